@@ -33,9 +33,13 @@ extern "C" {
 
 typedef struct sage2ov_ctx sage2ov_ctx;
 
+#define SAGE2OV_DEVICE_CURRENT (-1)
+#define SAGE2OV_DEVICE_NONE    (-2)  /* step-1-only context (what `-M 1` needs): parsing, canonical order, P.reads.
+                                        Every step 2/3 call on it fails with SAGE2OV_ERR_DEVICE. */
+
 typedef struct sage2ov_config {
     uint32_t min_overlap;   /* -k (main.cpp:424); hash string length h = min(k,64) (hashTable.cpp:78-81) */
-    int32_t  device;        /* HIP device ordinal; -1 = current device */
+    int32_t  device;        /* HIP device ordinal; SAGE2OV_DEVICE_CURRENT; SAGE2OV_DEVICE_NONE */
     uint32_t rank;          /* multi-GPU: this context's rank ...            */
     uint32_t world;         /* ... of `world` ranks (0 or 1 = single GPU)    */
     uint32_t host_threads;  /* OpenMP threads for host-side step 1 (0 = default) */

@@ -1,0 +1,938 @@
+// sage2_amd/csrc/sage2ov_device.hip -- hand-written HIP kernels for gfx950 (MI355X) and their launchers.
+//
+// Integer / bit / index work only (no MFMA): everything here is bound by HBM gathers.  Design notes
+// (layouts, algorithmic bytes, rooflines) are in DESIGN.md; reference citations are relative to the
+// SAGE2 tree.  Wavefront = 64 lanes everywhere; one wavefront owns one read in the probe kernel.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include "sage2ov.h"
+#include "sage2ov_internal.h"
+
+namespace s2 {
+
+#define HIPCHK(call)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess) {                                                                        \
+            char b_[512];                                                                              \
+            snprintf(b_, sizeof b_, "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+            err = b_;                                                                                  \
+            return SAGE2OV_ERR_DEVICE;                                                                 \
+        }                                                                                              \
+    } while (0)
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+struct Device {
+    int ordinal = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[8] = {};
+    // reads
+    u64 N = 0; int S = 0, maxL = 0, k = 0, h = 0;
+    u64* reads = nullptr;        // (N+1)*S words
+    // index
+    u64 T = 0; u64* slots = nullptr; u32* csr = nullptr; u64 n_csr = 0; u64 seed = 0x5A6E2D0Full;
+    u64 n_keys = 0, n_long = 0;
+    // per-read results
+    u64* right = nullptr; u64* left = nullptr; u32* conn = nullptr; u32* cflag = nullptr; uint8_t* status = nullptr;
+    // edge candidates
+    EdgeCand* cand = nullptr; u64 cand_cap = 0; u64* d_counters = nullptr;  // [0]=n_cand [1]=n_ov [2]=contained [3]=containedSize [4]=n_hits [5]=flag
+    u64 n_cand = 0;
+    // final edges (device resident)
+    FinalEdge* final_edges = nullptr; u64 n_final = 0;
+    DevTimings tm;
+};
+
+// =============================================================================================
+// device helpers
+// =============================================================================================
+__device__ __forceinline__ u64 rev2(u64 x) {   // reverse the order of the 32 two-bit groups
+    x = __brevll(x);
+    return ((x >> 1) & 0x5555555555555555ull) | ((x & 0x5555555555555555ull) << 1);
+}
+__device__ __forceinline__ u64 mask_top(int nb) {   // top 2*nb bits set, nb in [0,32]
+    return nb >= 32 ? ~0ull : (nb <= 0 ? 0ull : (~0ull << (64 - 2 * nb)));
+}
+// 64 bits of a big-endian bit string starting at bit `bitpos`; words beyond `nw` read as 0
+__device__ __forceinline__ u64 bits64(const u64* w, int nw, int bitpos) {
+    int q = bitpos >> 6, r = bitpos & 63;
+    u64 a = w[q];
+    if (r == 0) return a;
+    u64 b = (q + 1 < nw) ? w[q + 1] : 0ull;
+    return (a << r) | (b >> (64 - r));
+}
+// h-base key starting at base j, right aligned in (hi,lo): the integer (v0<<64|v1) of utils.cpp:171-187
+__device__ __forceinline__ void key_at(const u64* w, int nw, int j, int h, u64& hi, u64& lo) {
+    if (h <= 32) { hi = 0; lo = bits64(w, nw, 2 * j) >> (64 - 2 * h); }
+    else { hi = bits64(w, nw, 2 * j) >> (128 - 2 * h); lo = bits64(w, nw, 2 * j + 2 * h - 64); }
+}
+// reverse complement of an h-base key
+__device__ __forceinline__ void rc_key(u64 hi, u64 lo, int h, u64& rhi, u64& rlo) {
+    u64 a = rev2(lo), b = rev2(hi);          // (a:b) = 128-bit group-reversed value, key now in the top 2h bits
+    int sh = 128 - 2 * h;
+    u64 nh, nl;
+    if (sh >= 64) { nh = 0; nl = (sh == 64) ? a : (a >> (sh - 64)); }
+    else if (sh == 0) { nh = a; nl = b; }
+    else { nh = a >> sh; nl = (b >> sh) | (a << (64 - sh)); }
+    nh = ~nh; nl = ~nl;
+    if (2 * h <= 64) { nh = 0; if (2 * h < 64) nl &= (1ull << (2 * h)) - 1; }
+    else if (2 * h < 128) nh &= (1ull << (2 * h - 64)) - 1;
+    rhi = nh; rlo = nl;
+}
+__device__ __forceinline__ u64 mix64(u64 z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ u64 hash_key(u64 hi, u64 lo, u64 seed) {
+    return mix64((lo + seed) ^ mix64(hi + 0x9E3779B97F4A7C15ull));
+}
+__device__ __forceinline__ u32 tag_of(u64 hv) { u32 t = (u32)(hv & 0xFFFFFFu); return t ? t : 1u; }
+__device__ __forceinline__ u64 home_of(u64 hv, u64 T) { return __umul64hi(hv, T); }
+
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ u32 lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ u32 wave_incl_scan(u32 v) {
+    u32 lane = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { u32 t = __shfl_up(v, d); if (lane >= (u32)d) v += t; }
+    return v;
+}
+
+// look a key up: returns slot word (0 = not found / long bucket handled by caller)
+__device__ __forceinline__ u64 table_find(const u64* __restrict__ slots, u64 T, u64 hv) {
+    u64 idx = home_of(hv, T);
+    const u64 tag = tag_of(hv);
+    for (;;) {
+        u64 s = slots[idx];
+        if (s == 0) return 0;
+        if ((s >> SLOT_TAG_SHIFT) == tag) return s;
+        if (++idx == T) idx = 0;
+    }
+}
+
+// =============================================================================================
+// index build: count -> alloc -> fill -> sort (+ purity check of long buckets)
+// hashTable.cpp:70-128 semantics: multimap key -> entries in (id,type) order; >= 100 entries = long.
+// =============================================================================================
+__device__ __forceinline__ void entry_key(const u64* __restrict__ reads, int S, int h, u64 id, int t, u64& hi, u64& lo) {
+    const u64* w = reads + id * S;
+    int L = (int)(w[S - 1] & 0xFFFF);
+    u64 phi, plo;
+    if (t == 0 || t == 3) key_at(w, S, 0, h, phi, plo); else key_at(w, S, L - h, h, phi, plo);
+    if (t >= 2) rc_key(phi, plo, h, hi, lo); else { hi = phi; lo = plo; }   // hashTable.cpp:96-104
+}
+
+__global__ void k_index_count(const u64* __restrict__ reads, u64 N, int S, int h, u64 seed, u64* slots, u64 T, u32* cnt, u32* where) {
+    u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (; e < 4 * N; e += stride) {
+        u64 hi, lo; entry_key(reads, S, h, (e >> 2) + 1, (int)(e & 3), hi, lo);
+        u64 hv = hash_key(hi, lo, seed); const u64 tag = tag_of(hv); u64 idx = home_of(hv, T);
+        for (;;) {
+            u64 s = __hip_atomic_load(&slots[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (s == 0) {
+                u64 old = atomicCAS((u64*)&slots[idx], 0ull, tag << SLOT_TAG_SHIFT);
+                if (old == 0 || (old >> SLOT_TAG_SHIFT) == tag) break;
+            } else if ((s >> SLOT_TAG_SHIFT) == tag) break;
+            if (++idx == T) idx = 0;
+        }
+        atomicAdd(&cnt[idx], 1u);
+        where[e] = (u32)idx;
+    }
+}
+// counters: [0] csr total, [1] occupied slots, [2] number of big buckets, [3] impurity flag, [4] pure long buckets
+__global__ void k_index_alloc(u64* slots, u64 T, const u32* __restrict__ cnt, u64* counters, u64* big, u32 big_cap) {
+    u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u32 c = idx < T ? cnt[idx] : 0;
+    u32 need = c >= 2 ? c : 0;
+    // wave-aggregated allocation of CSR space
+    u32 incl = wave_incl_scan(need); u32 tot = __shfl(incl, 63);
+    u64 base = 0;
+    if (tot) { if (lane_id() == 63) base = atomicAdd(&counters[0], (u64)tot); base = __shfl(base, 63); }
+    u64 occ = __ballot(c != 0);
+    if (lane_id() == 0 && occ) atomicAdd(&counters[1], (u64)__popcll(occ));
+    if (c >= 2) {
+        u64 start = base + incl - need;
+        u32 c7 = c >= HASH_THRESHOLD ? SLOT_CNT_LONG : c;
+        slots[idx] = (slots[idx] & (~0ull << SLOT_TAG_SHIFT)) | ((u64)c7 << SLOT_CNT_SHIFT) | start;
+        if (c >= HASH_THRESHOLD) {
+            u64 b = atomicAdd(&counters[2], 1ull);
+            if (b < big_cap) { big[3 * b] = idx; big[3 * b + 1] = start; big[3 * b + 2] = c; }
+        }
+    }
+}
+__global__ void k_index_fill(u64 N, u64* slots, u32* cnt, const u32* __restrict__ where, u32* csr) {
+    u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (; e < 4 * N; e += stride) {
+        u64 idx = where[e]; u64 s = slots[idx];
+        u32 c7 = (u32)(s >> SLOT_CNT_SHIFT) & 127u;
+        u32 entry = (u32)(((e >> 2) + 1) * 4 + (e & 3));
+        if (c7 == 0) slots[idx] = (s & (~0ull << SLOT_TAG_SHIFT)) | (1ull << SLOT_CNT_SHIFT) | entry;   // the only entry: inline
+        else { u32 pos = atomicSub(&cnt[idx], 1u) - 1u; csr[(s & SLOT_PAY_MASK) + pos] = entry; }
+    }
+}
+__global__ void k_index_sort(const u64* __restrict__ slots, u64 T, u32* csr) {
+    u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= T) return;
+    u64 s = slots[idx]; u32 c7 = (u32)(s >> SLOT_CNT_SHIFT) & 127u;
+    if (c7 < 2 || c7 == SLOT_CNT_LONG) return;
+    u32* a = csr + (s & SLOT_PAY_MASK);
+    for (u32 i = 1; i < c7; i++) { u32 v = a[i]; int j = (int)i - 1; while (j >= 0 && a[j] > v) { a[j + 1] = a[j]; j--; } a[j + 1] = v; }
+}
+// one wave per big bucket: every entry must carry the same true key, else two keys were merged by
+// their 24-bit tags and the ">= 100 entries" verdict is not trustworthy -> ask for a reseed.
+__global__ void k_index_purity(const u64* __restrict__ reads, int S, int h, const u64* __restrict__ big, u64 nbig, const u32* __restrict__ csr, u64* counters) {
+    u64 b = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (b >= nbig) return;
+    u64 start = big[3 * b + 1], c = big[3 * b + 2];
+    u32 e0 = csr[start]; u64 hi0, lo0; entry_key(reads, S, h, e0 >> 2, e0 & 3, hi0, lo0);
+    bool bad = false;
+    for (u64 x = lane_id(); x < c; x += 64) { u32 e = csr[start + x]; u64 hi, lo; entry_key(reads, S, h, e >> 2, e & 3, hi, lo); if (hi != hi0 || lo != lo0) bad = true; }
+    if (__ballot(bad)) { if (lane_id() == 0) atomicAdd(&counters[3], 1ull); }
+    else if (lane_id() == 0) atomicAdd(&counters[4], 1ull);
+}
+__global__ void k_lookup(const u64* __restrict__ slots, u64 T, const u32* __restrict__ csr, u64 seed, u64 hi, u64 lo, u64* out, u32 cap) {
+    u64 s = table_find(slots, T, hash_key(hi, lo, seed));
+    u32 c7 = (u32)(s >> SLOT_CNT_SHIFT) & 127u;
+    if (s == 0 || c7 == SLOT_CNT_LONG) { out[0] = 0; return; }
+    out[0] = c7;
+    if (c7 == 1) { if (cap) out[1] = s & SLOT_PAY_MASK; return; }
+    for (u32 x = 0; x < c7 && x < cap; x++) out[1 + x] = csr[(s & SLOT_PAY_MASK) + x];
+}
+
+// =============================================================================================
+// exclusive scan of u32 (3 kernels, 2048 items per block)
+// =============================================================================================
+constexpr int SCAN_ITEMS = 8, SCAN_THREADS = 256, SCAN_BLOCK = SCAN_ITEMS * SCAN_THREADS;
+__device__ __forceinline__ u32 block_excl_scan(u32 v, u32* sh, u32& total) {   // sh: 4 words (one per wave)
+    u32 incl = wave_incl_scan(v); u32 w = threadIdx.x >> 6;
+    if (lane_id() == 63) sh[w] = incl;
+    __syncthreads();
+    u32 add = 0, t = 0;
+    for (u32 x = 0; x < SCAN_THREADS / 64; x++) { u32 s = sh[x]; if (x < w) add += s; t += s; }
+    __syncthreads();
+    total = t;
+    return add + incl - v;
+}
+__global__ void k_scan_reduce(const u32* __restrict__ in, u64 n, u64* partial) {
+    __shared__ u32 sh[4];
+    u64 base = (u64)blockIdx.x * SCAN_BLOCK + (u64)threadIdx.x * SCAN_ITEMS; u32 s = 0;
+    for (int i = 0; i < SCAN_ITEMS; i++) if (base + i < n) s += in[base + i];
+    u32 total; block_excl_scan(s, sh, total);
+    if (threadIdx.x == 0) partial[blockIdx.x] = total;
+}
+__global__ void k_scan_partials(u64* partial, u64 nb, u64* total_out) {   // single block
+    __shared__ u64 carry; __shared__ u64 shw[16];
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (u64 base = 0; base < nb; base += blockDim.x) {
+        u64 i = base + threadIdx.x; u64 v = i < nb ? partial[i] : 0;
+        // wave inclusive scan (u64)
+        u64 incl = v; u32 lane = lane_id();
+        for (int d = 1; d < 64; d <<= 1) { u64 t = __shfl_up(incl, d); if (lane >= (u32)d) incl += t; }
+        u32 w = threadIdx.x >> 6;
+        if (lane == 63) shw[w] = incl;
+        __syncthreads();
+        u64 add = 0, tot = 0;
+        for (u32 x = 0; x < blockDim.x / 64; x++) { u64 s = shw[x]; if (x < w) add += s; tot += s; }
+        u64 c = carry;
+        if (i < nb) partial[i] = c + add + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 0) carry = c + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total_out = carry;
+}
+__global__ void k_scan_final(const u32* __restrict__ in, u64 n, const u64* __restrict__ partial, u32* out) {
+    __shared__ u32 sh[4];
+    u64 base = (u64)blockIdx.x * SCAN_BLOCK + (u64)threadIdx.x * SCAN_ITEMS; u32 v[SCAN_ITEMS]; u32 s = 0;
+    for (int i = 0; i < SCAN_ITEMS; i++) { v[i] = base + i < n ? in[base + i] : 0; s += v[i]; }
+    u32 total; u32 ex = block_excl_scan(s, sh, total) + (u32)partial[blockIdx.x];
+    for (int i = 0; i < SCAN_ITEMS; i++) { if (base + i < n) out[base + i] = ex; ex += v[i]; }
+}
+
+// =============================================================================================
+// probe + verify + extension state machine  (economyGraph.cpp:72-451), one wavefront per read.
+// MODE 0: initial pass.  MODE 1: directional hit lists of status-0 reads (economyGraph.cpp:591-633).
+// =============================================================================================
+template <int S>
+struct WaveLds {
+    u64 x[2][S + 1];        // this read: forward strand, reverse complement (+1 zero pad word)
+    u64 y[S + 1][64];       // candidate reads, word-major so lane-consecutive (row S = zero pad)
+    u32 candJ[64], candE[64];
+    u32 hitR2[64], hitA[64], hitB[64];   // A: side | o<<1 | L2<<2 | j<<18 ; B: overhang length
+    u64 hitOv[S][64];       // overhang strings, left aligned
+};
+
+template <int S>
+__device__ __forceinline__ u64 ybits(const u64 (*y)[64], u32 lane, int bitpos) {
+    int q = bitpos >> 6, r = bitpos & 63;
+    u64 a = y[q][lane];
+    if (r == 0) return a;
+    return (a << r) | (y[q + 1][lane] >> (64 - r));
+}
+// n bases of X from xa equal n bases of candidate (lane column of y) from ya
+template <int S>
+__device__ __forceinline__ bool eq_range(const u64* x, int xa, const u64 (*y)[64], u32 lane, int ya, int n) {
+    for (int c = 0; c * 32 < n; c++) {
+        u64 a = bits64(x, S + 1, 2 * xa + 64 * c), b = ybits<S>(y, lane, 2 * ya + 64 * c);
+        if ((a ^ b) & mask_top(n - 32 * c)) return false;
+    }
+    return true;
+}
+
+struct ProbeArgs {
+    const u64* reads; u64 N; int S, k, h;
+    const u64* slots; u64 T; const u32* csr; u64 seed;
+    u64 lo, hi;                    // read id range [lo, hi)
+    u64* right; u64* left; u32* conn; u32* cflag;         // MODE 0 outputs
+    const uint8_t* status; Hit* hits; u64 hits_cap; u64* counters;   // MODE 1
+};
+
+template <int S, int MODE, int WPB>
+__global__ __launch_bounds__(64 * WPB) void k_probe(ProbeArgs A) {
+    __shared__ WaveLds<S> lds_all[WPB];
+    WaveLds<S>& W = lds_all[threadIdx.x >> 6];
+    const u32 lane = lane_id();
+    const u64 wave0 = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((u64)gridDim.x * blockDim.x) >> 6;
+    const int k = A.k, h = A.h;
+    if (lane <= 64 - 1) W.y[S][lane] = 0;
+
+    for (u64 i = A.lo + wave0; i < A.hi; i += nwaves) {
+        if (MODE == 1) { if (A.status[i] != 0) continue; }
+        // ---- stage the read and its reverse complement in LDS
+        wave_sync();
+        if (lane < S) W.x[0][lane] = A.reads[i * S + lane];
+        if (lane == S) { W.x[0][S] = 0; W.x[1][S] = 0; }
+        wave_sync();
+        const int L1 = (int)(W.x[0][S - 1] & 0xFFFF);
+        if (lane < S) {
+            int rem = L1 - 32 * (int)lane; u64 r;
+            if (rem <= 0) r = 0;
+            else if (rem >= 32) r = ~rev2(bits64(W.x[0], S + 1, 2 * (rem - 32)));
+            else r = (~rev2(W.x[0][0] >> (64 - 2 * rem))) & mask_top(rem);
+            W.x[1][lane] = r;
+        }
+        wave_sync();
+
+        // ---- extension state (uniform across the wave)
+        u64 rightId = 0, leftId = 0; u32 rightO = 0, leftO = 0, rightLen = 0, leftLen = 0;
+        u32 pRL = 0, pRov = 0, pLL = 0, pLov = 0; u64 pR[S], pL[S];
+#pragma unroll
+        for (int c = 0; c < S; c++) { pR[c] = 0; pL[c] = 0; }
+        int curJ = -1; bool mAR = false, mAL = false, mFR = false, ambR = false, ambL = false;
+        u32 connections = 0; u32 seq = 0;
+
+        const int nwin = L1 - h + 1;
+        for (int jb = 0; jb < nwin; jb += 64) {
+            // ---- probe: one window per lane
+            const int j = jb + (int)lane;
+            u32 cnt = 0; u32 pay = 0; bool inl = false;
+            if (j < nwin) {
+                u64 khi, klo; key_at(W.x[0], S + 1, j, h, khi, klo);
+                u64 s = table_find(A.slots, A.T, hash_key(khi, klo, A.seed));
+                u32 c7 = (u32)(s >> SLOT_CNT_SHIFT) & 127u;
+                if (s != 0 && c7 != SLOT_CNT_LONG) { cnt = c7; pay = (u32)(s & SLOT_PAY_MASK); inl = (c7 == 1); }
+            }
+            // ---- expand buckets into candidates, 64 at a time, in (window, bucket) order
+            u32 rem = cnt, cur = 0;
+            for (;;) {
+                u32 incl = wave_incl_scan(rem); u32 total = __shfl(incl, 63);
+                if (total == 0) break;
+                u32 excl = incl - rem, take = 0;
+                if (excl < 64 && rem) {
+                    take = min(rem, 64u - excl);
+                    for (u32 e = 0; e < take; e++) { W.candJ[excl + e] = (u32)j | (inl ? 0u : 0x80000000u); W.candE[excl + e] = inl ? pay : pay + cur + e; }
+                }
+                rem -= take; cur += take;
+                const u32 nb = min(total, 64u);
+                wave_sync();
+                // ---- verify: one candidate per lane
+                bool isHit = false; u32 hr2 = 0, hA = 0, hov = 0; u64 ovw[S];
+#pragma unroll
+                for (int c = 0; c < S; c++) ovw[c] = 0;
+                int hlen = 0; u32 htype = 0;
+                if (lane < nb) {
+                    u32 cj = W.candJ[lane], ce = W.candE[lane];
+                    u32 entry = (cj & 0x80000000u) ? A.csr[ce] : ce;
+                    const int jj = (int)(cj & 0x7FFFFFFFu);
+                    const u64 r2 = entry >> 2; const int t = entry & 3;
+                    const bool rightSide = (t == 0 || t == 2);
+                    bool gate = (r2 != i) && (rightSide ? (jj <= L1 - k) : (jj >= k - h));
+                    if (MODE == 1 && gate) gate = (A.status[r2] == 0);
+                    if (gate) {
+                        const u64* yp = A.reads + r2 * S;
+#pragma unroll
+                        for (int c = 0; c < S; c++) W.y[c][lane] = yp[c];
+                        const int L2 = (int)(W.y[S - 1][lane] & 0xFFFF);
+                        // overlap geometry (see DESIGN.md "mirrored compares"): region length n on both reads
+                        const int span = rightSide ? (L1 - jj) : (jj + h);      // bases of read i from the window to its end
+                        const bool cont = (L2 <= span);                          // read 2 ends inside read i
+                        const int n = cont ? L2 : span;
+                        bool eq;
+                        if (t == 0)      eq = eq_range<S>(W.x[0], jj, W.y, lane, 0, n);
+                        else if (t == 3) eq = eq_range<S>(W.x[1], L1 - jj - h, W.y, lane, 0, n);
+                        else if (t == 2) eq = eq_range<S>(W.x[1], L1 - jj - n, W.y, lane, L2 - n, n);
+                        else             eq = eq_range<S>(W.x[0], jj + h - n, W.y, lane, L2 - n, n);
+                        if (MODE == 0) {
+                            if (eq && cont) atomicOr(&A.cflag[r2], i > r2 ? 1u : 2u);     // economyGraph.cpp:735
+                            if (eq && !cont) {
+                                isHit = true; hr2 = (u32)r2; hov = (u32)(L2 - n);
+                                hA = (rightSide ? 0u : 1u) | ((u32)((t == 2 || t == 3) ? 1 : 0) << 1) | ((u32)L2 << 2) | ((u32)jj << 18);
+                                const int ov = L2 - n;
+                                if (t == 0 || t == 3) {   // overhang = tail of read 2
+#pragma unroll
+                                    for (int c = 0; c < S; c++) if (32 * c < ov) ovw[c] = ybits<S>(W.y, lane, 2 * n + 64 * c) & mask_top(ov - 32 * c);
+                                } else {                  // overhang = reverse complement of the head of read 2
+#pragma unroll
+                                    for (int c = 0; c < S; c++) {
+                                        int rm = ov - 32 * c;
+                                        if (rm >= 32) ovw[c] = ~rev2(ybits<S>(W.y, lane, 2 * (rm - 32)));
+                                        else if (rm > 0) ovw[c] = (~rev2(W.y[0][lane] >> (64 - 2 * rm))) & mask_top(rm);
+                                    }
+                                }
+                            }
+                        } else {
+                            if (eq) {   // economyGraph.cpp:607-626: contained-and-equal counts as a hit here
+                                isHit = true; hr2 = (u32)r2;
+                                hlen = rightSide ? (L2 - (L1 - jj)) : (L2 - jj - h);
+                                htype = t == 0 ? 3u : (t == 1 ? 0u : (t == 2 ? 2u : 1u));
+                            }
+                        }
+                    }
+                }
+                const u64 hb = __ballot(isHit);
+                const u32 nh = (u32)__popcll(hb);
+                const u32 hidx = (u32)__popcll(hb & ((1ull << lane) - 1ull));
+                if (MODE == 1) {
+                    if (nh) {
+                        u64 base = 0; if (lane == 0) base = atomicAdd(&A.counters[4], (u64)nh); base = __shfl(base, 0);
+                        if (isHit && base + hidx < A.hits_cap) {
+                            Hit hh; hh.from = (u32)i; hh.to = hr2; hh.len = hlen; hh.seq_hi = 0; hh.type = (uint8_t)htype; hh.pad = 0; hh.seq = seq + hidx;
+                            A.hits[base + hidx] = hh;
+                        }
+                        seq += nh;
+                    }
+                    wave_sync();
+                    continue;
+                }
+                if (isHit) {
+                    W.hitR2[hidx] = hr2; W.hitA[hidx] = hA; W.hitB[hidx] = hov;
+#pragma unroll
+                    for (int c = 0; c < S; c++) W.hitOv[c][hidx] = ovw[c];
+                }
+                wave_sync();
+                // ---- sequential extension state machine over the verified hits (economyGraph.cpp:95-438)
+                for (u32 x = 0; x < nh; x++) {
+                    const u32 a = W.hitA[x], ov = W.hitB[x]; const u64 r2 = W.hitR2[x];
+                    const bool isLeft = a & 1; const u32 o = (a >> 1) & 1, L2 = (a >> 2) & 0xFFFF; const int jj = (int)(a >> 18);
+                    u64 q[S];
+#pragma unroll
+                    for (int c = 0; c < S; c++) q[c] = W.hitOv[c][x];
+                    if (jj != curJ) { curJ = jj; mAR = mAL = mFR = false; }
+                    connections++;
+                    if (!isLeft) {
+                        if (rightId == 0) { rightId = r2; rightO = o; rightLen = ov; pRL = L2; pRov = ov; mAR = true; mFR = true;
+#pragma unroll
+                            for (int c = 0; c < S; c++) pR[c] = q[c];
+                        } else {
+                            const int m = (int)min(pRov, ov); bool cons = true;
+#pragma unroll
+                            for (int c = 0; c < S; c++) if (32 * c < m && ((pR[c] ^ q[c]) & mask_top(m - 32 * c))) cons = false;
+                            if (cons) {
+                                bool upd = false;
+                                if (mAR) { if (L2 > pRL) { if (mFR) { rightId = r2; rightO = o; rightLen = ov; } upd = true; } }
+                                else { upd = true; mAR = true; }
+                                if (upd) { pRL = L2; pRov = ov;
+#pragma unroll
+                                    for (int c = 0; c < S; c++) pR[c] = q[c];
+                                }
+                            } else ambR = true;
+                        }
+                    } else {
+                        if (leftId == 0) { leftId = r2; leftO = o; leftLen = ov; pLL = L2; pLov = ov; mAL = true;
+#pragma unroll
+                            for (int c = 0; c < S; c++) pL[c] = q[c];
+                        } else {
+                            const int m = (int)min(pLov, ov); bool cons = true;
+#pragma unroll
+                            for (int c = 0; c < S; c++) if (32 * c < m && ((pL[c] ^ q[c]) & mask_top(m - 32 * c))) cons = false;
+                            if (cons) {
+                                bool upd = false;
+                                if (mAL) { if (L2 > pLL) upd = true; } else { upd = true; mAL = true; }
+                                if (upd) { leftId = r2; leftO = o; leftLen = ov; pLL = L2; pLov = ov;
+#pragma unroll
+                                    for (int c = 0; c < S; c++) pL[c] = q[c];
+                                }
+                            } else ambL = true;
+                        }
+                    }
+                }
+                wave_sync();
+            }
+        }
+        if (MODE == 0 && lane == 0) {
+            if (ambR || ambL) { rightLen = 0; leftLen = 0; }                                        // economyGraph.cpp:446-450
+            A.right[i] = rightId | ((u64)rightO << 40) | ((u64)(rightLen & 0x3FFFFFu) << 42);
+            A.left[i] = leftId | ((u64)leftO << 40) | ((u64)(leftLen & 0x3FFFFFu) << 42);
+            A.conn[i] = connections;
+        }
+    }
+}
+
+// =============================================================================================
+// reciprocal pass (economyGraph.cpp:455-480), order-independent restatement:
+//   cond(i) does not depend on the serial order; the `exploredReads[x]!=4` test at the time read i
+//   is visited is true iff NOT (x < i and cond(x)).
+// =============================================================================================
+constexpr u64 ID_MASK = (1ull << 40) - 1;
+__global__ void k_recip_cond(u64 N, const u64* __restrict__ right, const u64* __restrict__ left, const u32* __restrict__ conn,
+                             const u32* __restrict__ cflag, uint8_t* status, u64* counters) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x + 1;
+    u32 c = 0; bool cond = false, is6 = false;
+    if (i <= N) {
+        c = conn[i]; u32 cf = cflag[i]; bool over = c > CONN_LIMIT;
+        is6 = (cf & 1u) || ((cf & 2u) && !over);        // single-thread outcome of the :444 / :735 writes
+        u64 l = left[i], r = right[i]; u64 lid = l & ID_MASK, rid = r & ID_MASK;
+        if (!is6 && (l >> 42) != 0 && (r >> 42) != 0) {
+            bool lrec = ((right[lid] & ID_MASK) == i) || ((left[lid] & ID_MASK) == i);
+            bool rrec = ((right[rid] & ID_MASK) == i) || ((left[rid] & ID_MASK) == i);
+            cond = lrec && rrec;
+        }
+        status[i] = cond ? 4 : (is6 ? 6 : (over ? 5 : 0));
+    }
+    // block reductions of the log counters
+    u64 ov = c; for (int d = 32; d; d >>= 1) ov += __shfl_xor(ov, d);
+    u64 bc = __ballot(cond), b6 = __ballot(is6);
+    if (lane_id() == 0) { if (ov) atomicAdd(&counters[1], ov); if (bc) atomicAdd(&counters[2], (u64)__popcll(bc)); if (b6) atomicAdd(&counters[3], (u64)__popcll(b6)); }
+}
+__device__ __forceinline__ u32 flip_type(u32 t) { return t == 0 ? 3u : (t == 3 ? 0u : t); }   // utils.cpp:212
+__device__ __forceinline__ void emit_edge(EdgeCand* cand, u64 cap, u64* counters, const u64* reads, int S, u64 u, u64 v, u32 delta, u32 type) {
+    if (u == v) return;                                                                    // economyGraph.cpp:815
+    EdgeCand e;
+    if (u < v) { e.from = (u32)u; e.to = (u32)v; e.len = delta & 0xFFFFFu; e.type = type; }
+    else {                                                                                  // the twin lives in the smaller id's list
+        int Lu = (int)(reads[u * S + S - 1] & 0xFFFF), Lv = (int)(reads[v * S + S - 1] & 0xFFFF);
+        e.from = (u32)v; e.to = (u32)u; e.len = (u32)(Lu - (Lv - (int)delta)) & 0xFFFFFu; e.type = flip_type(type);   // economyGraph.cpp:821
+    }
+    u64 p = atomicAdd(&counters[0], 1ull);
+    if (p < cap) cand[p] = e;
+}
+__global__ void k_recip_emit(u64 N, const u64* __restrict__ reads, int S, const u64* __restrict__ right, const u64* __restrict__ left,
+                             const uint8_t* __restrict__ status, EdgeCand* cand, u64 cap, u64* counters) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x + 1;
+    if (i > N || status[i] != 4) return;
+    u64 l = left[i], r = right[i]; u64 lid = l & ID_MASK, rid = r & ID_MASK;
+    if (!(lid < i && status[lid] == 4)) emit_edge(cand, cap, counters, reads, S, i, lid, (u32)(l >> 42), ((l >> 40) & 3) == 0 ? 0u : 1u);   // :462-467
+    if (!(rid < i && status[rid] == 4)) emit_edge(cand, cap, counters, reads, S, i, rid, (u32)(r >> 42), ((r >> 40) & 3) == 0 ? 3u : 2u);   // :468-473
+}
+
+// reduce-phase support: the host replay needs the lists of unresolved reads and of their neighbours
+__global__ void k_red_mark(const EdgeCand* __restrict__ cand, u64 n, const uint8_t* __restrict__ status, uint8_t* need) {
+    u64 x = (u64)blockIdx.x * blockDim.x + threadIdx.x; if (x >= n) return;
+    EdgeCand e = cand[x];
+    if (status[e.from] == 0 || status[e.to] == 0) { need[e.from] = 1; need[e.to] = 1; }
+}
+__global__ void k_red_collect(EdgeCand* cand, u64 n, const uint8_t* __restrict__ status, const uint8_t* __restrict__ need, EdgeCand* out, u64 cap, u64* counter) {
+    u64 x = (u64)blockIdx.x * blockDim.x + threadIdx.x; if (x >= n) return;
+    EdgeCand e = cand[x];
+    if (need[e.from] || need[e.to]) { u64 p = atomicAdd(counter, 1ull); if (p < cap) out[p] = e; }
+    if (status[e.from] == 0) cand[x].type = e.type | 0x80u;    // list of an unresolved read: rewritten by the replay
+}
+__global__ void k_red_unresolved(u64 N, const uint8_t* __restrict__ status, u32* out, u64 cap, u64* counter) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x + 1; if (i > N) return;
+    if (status[i] == 0) { u64 p = atomicAdd(counter, 1ull); if (p < cap) out[p] = (u32)i; }
+}
+
+// =============================================================================================
+// sortEconomyGraph + convertGraph (economyGraph.cpp:896, overlapGraph.cpp:84-111) on the candidate list
+// =============================================================================================
+__global__ void k_conv_degree(const EdgeCand* __restrict__ cand, u64 n, u32* deg) {
+    u64 x = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x < n && !(cand[x].type & 0x80u)) atomicAdd(&deg[cand[x].from], 1u);
+}
+__global__ void k_conv_fill(const EdgeCand* __restrict__ cand, u64 n, const u32* __restrict__ offs, u32* cursor, u64* keys) {
+    u64 x = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= n) return;
+    EdgeCand e = cand[x]; if (e.type & 0x80u) return;
+    u32 p = atomicAdd(&cursor[e.from], 1u);
+    keys[offs[e.from] + p] = ((u64)e.to << 22) | ((u64)e.type << 20) | e.len;      // ascending = compareIdBased (economyGraph.cpp:875)
+}
+__global__ void k_conv_sort(u64 N, const u32* __restrict__ offs, const u32* __restrict__ deg, u64* keys, u32* keep) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > N) return;
+    u32 d = deg[i]; if (!d) return;
+    u64* a = keys + offs[i]; u32* kp = keep + offs[i];
+    for (u32 x = 1; x < d; x++) { u64 v = a[x]; int j = (int)x - 1; while (j >= 0 && a[j] > v) { a[j + 1] = a[j]; j--; } a[j + 1] = v; }
+    for (u32 x = 0; x < d; x++) kp[x] = (x == 0 || (a[x] >> 20) != (a[x - 1] >> 20)) ? 1u : 0u;   // overlapGraph.cpp:101
+}
+__global__ void k_conv_owner(u64 N, const u32* __restrict__ offs, const u32* __restrict__ deg, u32* owner) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > N) return;
+    u32 d = deg[i]; for (u32 x = 0; x < d; x++) owner[offs[i] + x] = (u32)i;
+}
+__global__ void k_conv_emit(u64 n, const u64* __restrict__ keys, const u32* __restrict__ keep, const u32* __restrict__ pos, const u32* __restrict__ owner,
+                            const u64* __restrict__ reads, int S, FinalEdge* out) {
+    u64 x = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= n || !keep[x]) return;
+    u64 kx = keys[x]; FinalEdge f; f.from = owner[x]; f.to = (u32)(kx >> 22); f.type = (u32)(kx >> 20) & 3u; f.len = (u32)(kx & 0xFFFFFu);
+    u32 Lu = (u32)(reads[(u64)f.from * S + S - 1] & 0xFFFF), Lv = (u32)(reads[(u64)f.to * S + S - 1] & 0xFFFF);
+    f.len_twin = Lu - (Lv - f.len);                                                         // overlapGraph.cpp:145-148 (u32 arithmetic)
+    out[pos[x]] = f;
+}
+
+// =============================================================================================
+// host-side launchers
+// =============================================================================================
+static inline unsigned grid_for(u64 n, unsigned block) { return (unsigned)std::max<u64>(1, (n + block - 1) / block); }
+
+Device* dev_create(int ordinal, std::string& err) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0) { err = std::string("no HIP device available: ") + hipGetErrorString(e); return nullptr; }
+    int dev = ordinal;
+    if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) dev = 0; }
+    if (dev >= count) { err = "device ordinal out of range"; return nullptr; }
+    if (hipSetDevice(dev) != hipSuccess) { err = "hipSetDevice failed"; return nullptr; }
+    Device* d = new Device(); d->ordinal = dev;
+    if (hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess) { err = "hipStreamCreate failed"; delete d; return nullptr; }
+    for (auto& ev : d->ev) hipEventCreate(&ev);
+    if (hipMalloc(&d->d_counters, 16 * sizeof(u64)) != hipSuccess) { err = "hipMalloc(counters) failed"; delete d; return nullptr; }
+    hipMemset(d->d_counters, 0, 16 * sizeof(u64));
+    return d;
+}
+static void free_reads(Device* d) {
+    hipFree(d->reads); hipFree(d->slots); hipFree(d->csr); hipFree(d->right); hipFree(d->left); hipFree(d->conn); hipFree(d->cflag);
+    hipFree(d->status); hipFree(d->cand); hipFree(d->final_edges);
+    d->reads = d->slots = nullptr; d->csr = nullptr; d->right = d->left = nullptr; d->conn = d->cflag = nullptr; d->status = nullptr; d->cand = nullptr; d->final_edges = nullptr;
+}
+void dev_destroy(Device* d) {
+    if (!d) return;
+    hipSetDevice(d->ordinal);
+    hipStreamSynchronize(d->stream);
+    free_reads(d); hipFree(d->d_counters);
+    for (auto& ev : d->ev) if (ev) hipEventDestroy(ev);
+    hipStreamDestroy(d->stream);
+    delete d;
+}
+void* dev_stream(Device* d) { return (void*)d->stream; }
+int dev_sync(Device* d, std::string& err) { HIPCHK(hipStreamSynchronize(d->stream)); return 0; }
+void dev_timings(Device* d, DevTimings* t) { *t = d->tm; }
+void dev_reset_timings(Device* d) { d->tm = DevTimings(); }
+
+int dev_upload_reads(Device* d, const uint64_t* words, uint64_t N, int S, int maxL, int k, std::string& err) {
+    HIPCHK(hipSetDevice(d->ordinal));
+    if (S != 4 && S != 8 && S != 16) { err = "unsupported words-per-read (read length limit is 504 bases)"; return SAGE2OV_ERR_LIMIT; }
+    if (N >= (1ull << 30)) { err = "more than 2^30-1 unique reads per context is not supported yet"; return SAGE2OV_ERR_LIMIT; }
+    free_reads(d);
+    d->N = N; d->S = S; d->maxL = maxL; d->k = k; d->h = k > 64 ? 64 : k;
+    HIPCHK(hipMalloc(&d->reads, (N + 1) * S * sizeof(u64)));
+    HIPCHK(hipMemcpyAsync(d->reads, words, (N + 1) * S * sizeof(u64), hipMemcpyHostToDevice, d->stream));
+    HIPCHK(hipMalloc(&d->right, (N + 1) * sizeof(u64))); HIPCHK(hipMalloc(&d->left, (N + 1) * sizeof(u64)));
+    HIPCHK(hipMalloc(&d->conn, (N + 1) * sizeof(u32))); HIPCHK(hipMalloc(&d->cflag, (N + 1) * sizeof(u32)));
+    HIPCHK(hipMalloc(&d->status, (N + 1)));
+    d->cand_cap = 2 * N + 1024;
+    HIPCHK(hipMalloc(&d->cand, d->cand_cap * sizeof(EdgeCand)));
+    HIPCHK(hipStreamSynchronize(d->stream));
+    return 0;
+}
+
+int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t* csr_out, uint64_t* nlong_out, uint32_t* rebuilds, std::string& err) {
+    HIPCHK(hipSetDevice(d->ordinal));
+    const u64 N = d->N; if (!d->reads) { err = "reads not resident"; return SAGE2OV_ERR_ARG; }
+    hipFree(d->slots); hipFree(d->csr); d->slots = nullptr; d->csr = nullptr;
+    d->T = std::max<u64>(1024, 8 * N);                                   // load <= 0.5, as hashTable.cpp:83 sizes it
+    if (d->T >= (1ull << 32)) { err = "table too large for 32-bit slot indices"; return SAGE2OV_ERR_LIMIT; }
+    HIPCHK(hipMalloc(&d->slots, d->T * sizeof(u64)));
+    u32 *cnt = nullptr, *where = nullptr; u64* big = nullptr; const u32 big_cap = 1u << 20;
+    HIPCHK(hipMalloc(&cnt, d->T * sizeof(u32))); HIPCHK(hipMalloc(&where, std::max<u64>(1, 4 * N) * sizeof(u32)));
+    HIPCHK(hipMalloc(&big, (u64)big_cap * 3 * sizeof(u64)));
+    HIPCHK(hipMalloc(&d->csr, std::max<u64>(1, 4 * N) * sizeof(u32)));
+    HIPCHK(hipEventRecord(d->ev[0], d->stream));
+    *rebuilds = 0;
+    for (int attempt = 0;; attempt++) {
+        HIPCHK(hipMemsetAsync(d->slots, 0, d->T * sizeof(u64), d->stream));
+        HIPCHK(hipMemsetAsync(cnt, 0, d->T * sizeof(u32), d->stream));
+        HIPCHK(hipMemsetAsync(d->d_counters + 8, 0, 5 * sizeof(u64), d->stream));
+        const unsigned gE = (unsigned)std::min<u64>(grid_for(4 * N, 256), 256 * 64);
+        hipLaunchKernelGGL(k_index_count, dim3(gE), dim3(256), 0, d->stream, d->reads, N, d->S, d->h, d->seed, d->slots, d->T, cnt, where);
+        hipLaunchKernelGGL(k_index_alloc, dim3(grid_for(d->T, 256)), dim3(256), 0, d->stream, d->slots, d->T, cnt, d->d_counters + 8, big, big_cap);
+        hipLaunchKernelGGL(k_index_fill, dim3(gE), dim3(256), 0, d->stream, N, d->slots, cnt, where, d->csr);
+        hipLaunchKernelGGL(k_index_sort, dim3(grid_for(d->T, 256)), dim3(256), 0, d->stream, d->slots, d->T, d->csr);
+        u64 c[5];
+        HIPCHK(hipMemcpyAsync(c, d->d_counters + 8, sizeof c, hipMemcpyDeviceToHost, d->stream));
+        HIPCHK(hipStreamSynchronize(d->stream));
+        if (c[2] > big_cap) { err = "too many long buckets"; hipFree(cnt); hipFree(where); hipFree(big); return SAGE2OV_ERR_LIMIT; }
+        if (c[2]) {
+            hipLaunchKernelGGL(k_index_purity, dim3(grid_for(c[2] * 64, 256)), dim3(256), 0, d->stream, d->reads, d->S, d->h, big, c[2], d->csr, d->d_counters + 8);
+            HIPCHK(hipMemcpyAsync(c, d->d_counters + 8, sizeof c, hipMemcpyDeviceToHost, d->stream));
+            HIPCHK(hipStreamSynchronize(d->stream));
+        }
+        if (c[3] == 0) { d->n_csr = c[0]; d->n_keys = c[1]; d->n_long = c[2]; break; }
+        if (attempt >= 8) { err = "index build: tag collisions in long buckets persist after 8 reseeds"; hipFree(cnt); hipFree(where); hipFree(big); return SAGE2OV_ERR_INTERNAL; }
+        d->seed = d->seed * 0x9E3779B97F4A7C15ull + 12345; (*rebuilds)++;
+    }
+    HIPCHK(hipEventRecord(d->ev[1], d->stream));
+    HIPCHK(hipStreamSynchronize(d->stream));
+    float ms = 0; hipEventElapsedTime(&ms, d->ev[0], d->ev[1]); d->tm.index_ms += ms;
+    hipFree(cnt); hipFree(where); hipFree(big);
+    *slots_out = d->T; *keys_out = d->n_keys; *csr_out = d->n_csr; *nlong_out = d->n_long;
+    return 0;
+}
+
+int dev_lookup(Device* d, uint64_t hi, uint64_t lo, uint64_t* entries, uint32_t cap, uint32_t* count, std::string& err) {
+    HIPCHK(hipSetDevice(d->ordinal));
+    if (!d->slots) { err = "index not built"; return SAGE2OV_ERR_ARG; }
+    u64* out = nullptr; const u32 c2 = std::min<u32>(cap, 128);
+    HIPCHK(hipMalloc(&out, (129) * sizeof(u64)));
+    hipLaunchKernelGGL(k_lookup, dim3(1), dim3(1), 0, d->stream, d->slots, d->T, d->csr, d->seed, (u64)hi, (u64)lo, out, c2);
+    u64 host[129];
+    HIPCHK(hipMemcpyAsync(host, out, sizeof host, hipMemcpyDeviceToHost, d->stream));
+    HIPCHK(hipStreamSynchronize(d->stream));
+    hipFree(out);
+    *count = (u32)host[0];
+    for (u32 x = 0; x < *count && x < c2; x++) entries[x] = host[1 + x];
+    return 0;
+}
+
+template <int MODE>
+static int launch_probe(Device* d, ProbeArgs& A, std::string& err) {
+    const u64 nreads = A.hi - A.lo; if (nreads == 0) return 0;
+    // one wave per read, 4 waves per block (2 for the 16-word layout: LDS); enough blocks to fill
+    // 256 CUs several times over, grid-stride beyond
+    const unsigned wpb = d->S == 16 ? 2 : 4;
+    const unsigned blocks = (unsigned)std::min<u64>((nreads + wpb - 1) / wpb, 256ull * 32);
+    switch (d->S) {
+        case 4: hipLaunchKernelGGL((k_probe<4, MODE, 4>), dim3(blocks), dim3(256), 0, d->stream, A); break;
+        case 8: hipLaunchKernelGGL((k_probe<8, MODE, 4>), dim3(blocks), dim3(256), 0, d->stream, A); break;
+        case 16: hipLaunchKernelGGL((k_probe<16, MODE, 2>), dim3(blocks), dim3(128), 0, d->stream, A); break;
+        default: err = "bad S"; return SAGE2OV_ERR_INTERNAL;
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+static ProbeArgs base_args(Device* d) {
+    ProbeArgs A; memset(&A, 0, sizeof A);
+    A.reads = d->reads; A.N = d->N; A.S = d->S; A.k = d->k; A.h = d->h; A.slots = d->slots; A.T = d->T; A.csr = d->csr; A.seed = d->seed;
+    A.right = d->right; A.left = d->left; A.conn = d->conn; A.cflag = d->cflag; A.status = d->status; A.counters = d->d_counters;
+    return A;
+}
+
+int dev_probe(Device* d, uint64_t lo, uint64_t hi, std::string& err) {
+    HIPCHK(hipSetDevice(d->ordinal));
+    if (!d->slots) { err = "index not built"; return SAGE2OV_ERR_ARG; }
+    const u64 N = d->N;
+    HIPCHK(hipEventRecord(d->ev[0], d->stream));
+    HIPCHK(hipMemsetAsync(d->right, 0, (N + 1) * sizeof(u64), d->stream)); HIPCHK(hipMemsetAsync(d->left, 0, (N + 1) * sizeof(u64), d->stream));
+    HIPCHK(hipMemsetAsync(d->conn, 0, (N + 1) * sizeof(u32), d->stream)); HIPCHK(hipMemsetAsync(d->cflag, 0, (N + 1) * sizeof(u32), d->stream));
+    ProbeArgs A = base_args(d); A.lo = lo; A.hi = hi;
+    HIPCHK(hipEventRecord(d->ev[2], d->stream));
+    int rc = launch_probe<0>(d, A, err); if (rc) return rc;
+    HIPCHK(hipEventRecord(d->ev[3], d->stream));
+    HIPCHK(hipEventRecord(d->ev[1], d->stream));
+    HIPCHK(hipStreamSynchronize(d->stream));
+    float ms = 0; hipEventElapsedTime(&ms, d->ev[0], d->ev[1]); d->tm.probe_ms += ms;
+    hipEventElapsedTime(&ms, d->ev[2], d->ev[3]); d->tm.probe_kernel_ms += ms; d->tm.probe_launches++;
+    return 0;
+}
+
+struct Record { u64 right, left; u32 conn, cflag; };
+__global__ void k_pack_records(u64 lo, u64 hi, const u64* right, const u64* left, const u32* conn, const u32* cflag, Record* out) {
+    u64 i = lo + (u64)blockIdx.x * blockDim.x + threadIdx.x; if (i >= hi) return;
+    Record r; r.right = right[i]; r.left = left[i]; r.conn = conn[i]; r.cflag = cflag[i]; out[i - lo] = r;
+}
+__global__ void k_unpack_records(u64 first, u64 n, const Record* in, u64* right, u64* left, u32* conn, u32* cflag, bool own) {
+    u64 x = (u64)blockIdx.x * blockDim.x + threadIdx.x; if (x >= n) return;
+    Record r = in[x]; u64 i = first + x; right[i] = r.right; left[i] = r.left; conn[i] = r.conn;
+    (void)own; cflag[i] = r.cflag;
+}
+int dev_export_records(Device* d, void* dst, uint64_t lo, uint64_t hi, std::string& err) {
+    HIPCHK(hipSetDevice(d->ordinal));
+    if (hi > lo) hipLaunchKernelGGL(k_pack_records, dim3(grid_for(hi - lo, 256)), dim3(256), 0, d->stream, (u64)lo, (u64)hi, d->right, d->left, d->conn, d->cflag, (Record*)dst);
+    HIPCHK(hipStreamSynchronize(d->stream));
+    return 0;
+}
+int dev_import_records(Device* d, const void* src, uint64_t first, uint64_t n, std::string& err) {
+    HIPCHK(hipSetDevice(d->ordinal));
+    if (n) hipLaunchKernelGGL(k_unpack_records, dim3(grid_for(n, 256)), dim3(256), 0, d->stream, (u64)first, (u64)n, (const Record*)src, d->right, d->left, d->conn, d->cflag, false);
+    HIPCHK(hipStreamSynchronize(d->stream));
+    return 0;
+}
+
+int dev_reciprocal(Device* d, uint64_t* n_ov, uint64_t* contained, uint64_t* contained_size, std::string& err) {
+    HIPCHK(hipSetDevice(d->ordinal));
+    const u64 N = d->N;
+    HIPCHK(hipEventRecord(d->ev[0], d->stream));
+    HIPCHK(hipMemsetAsync(d->d_counters, 0, 8 * sizeof(u64), d->stream));
+    HIPCHK(hipMemsetAsync(d->status, 0, N + 1, d->stream));
+    hipLaunchKernelGGL(k_recip_cond, dim3(grid_for(N, 256)), dim3(256), 0, d->stream, N, d->right, d->left, d->conn, d->cflag, d->status, d->d_counters);
+    hipLaunchKernelGGL(k_recip_emit, dim3(grid_for(N, 256)), dim3(256), 0, d->stream, N, d->reads, d->S, d->right, d->left, d->status, d->cand, d->cand_cap, d->d_counters);
+    u64 c[8];
+    HIPCHK(hipMemcpyAsync(c, d->d_counters, sizeof c, hipMemcpyDeviceToHost, d->stream));
+    HIPCHK(hipEventRecord(d->ev[1], d->stream));
+    HIPCHK(hipStreamSynchronize(d->stream));
+    float ms = 0; hipEventElapsedTime(&ms, d->ev[0], d->ev[1]); d->tm.reciprocal_ms += ms;
+    if (c[0] > d->cand_cap) { err = "edge candidate buffer overflow"; return SAGE2OV_ERR_INTERNAL; }
+    d->n_cand = c[0]; *n_ov = c[1]; *contained = c[2]; *contained_size = c[3];
+    return 0;
+}
+
+int dev_download_initial(Device* d, uint64_t* right, uint64_t* left, uint8_t* status, uint32_t* conn, std::string& err) {
+    HIPCHK(hipSetDevice(d->ordinal));
+    const u64 N = d->N;
+    if (right) HIPCHK(hipMemcpy(right, d->right, (N + 1) * sizeof(u64), hipMemcpyDeviceToHost));
+    if (left) HIPCHK(hipMemcpy(left, d->left, (N + 1) * sizeof(u64), hipMemcpyDeviceToHost));
+    if (status) HIPCHK(hipMemcpy(status, d->status, N + 1, hipMemcpyDeviceToHost));
+    if (conn) HIPCHK(hipMemcpy(conn, d->conn, (N + 1) * sizeof(u32), hipMemcpyDeviceToHost));
+    return 0;
+}
+int dev_download_status(Device* d, std::vector<uint8_t>& status, std::string& err) {
+    HIPCHK(hipSetDevice(d->ordinal));
+    status.resize(d->N + 1);
+    HIPCHK(hipMemcpy(status.data(), d->status, d->N + 1, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int dev_unresolved_ids(Device* d, std::vector<uint32_t>& ids, std::string& err);
+int dev_unresolved_hits(Device* d, std::vector<Hit>& hits, uint64_t* n_unresolved, std::string& err) {
+    HIPCHK(hipSetDevice(d->ordinal));
+    const u64 N = d->N;
+    HIPCHK(hipEventRecord(d->ev[0], d->stream));
+    std::vector<uint32_t> ids; int rc = dev_unresolved_ids(d, ids, err); if (rc) return rc;
+    u64 nun = ids.size();
+    *n_unresolved = nun; hits.clear();
+    if (nun == 0) return 0;
+    u64 cap = std::max<u64>(1 << 16, nun * 80);
+    for (int attempt = 0; attempt < 4; attempt++) {
+        Hit* dh = nullptr;
+        HIPCHK(hipMalloc(&dh, cap * sizeof(Hit)));
+        HIPCHK(hipMemsetAsync(d->d_counters + 4, 0, sizeof(u64), d->stream));
+        ProbeArgs A = base_args(d); A.lo = 1; A.hi = N + 1; A.hits = dh; A.hits_cap = cap;
+        rc = launch_probe<1>(d, A, err); if (rc) { hipFree(dh); return rc; }
+        u64 nh = 0;
+        HIPCHK(hipMemcpyAsync(&nh, d->d_counters + 4, sizeof nh, hipMemcpyDeviceToHost, d->stream));
+        HIPCHK(hipStreamSynchronize(d->stream));
+        if (nh <= cap) {
+            hits.resize(nh);
+            if (nh) HIPCHK(hipMemcpy(hits.data(), dh, nh * sizeof(Hit), hipMemcpyDeviceToHost));
+            hipFree(dh);
+            HIPCHK(hipEventRecord(d->ev[1], d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
+            float ms = 0; hipEventElapsedTime(&ms, d->ev[0], d->ev[1]); d->tm.hits_ms += ms;
+            return 0;
+        }
+        hipFree(dh); cap = nh + 1024;
+    }
+    err = "hit buffer sizing failed"; return SAGE2OV_ERR_INTERNAL;
+}
+
+// candidates that touch an unresolved read or one of its neighbours (their adjacency lists are what
+// markTransitiveEdge reads, economyGraph.cpp:643-679); candidates owned by unresolved reads are flagged
+// as dropped on the device: the replay re-emits the survivors.
+int dev_collect_reduce_edges(Device* d, std::vector<EdgeCand>& out, std::string& err) {
+    HIPCHK(hipSetDevice(d->ordinal));
+    out.clear(); const u64 n = d->n_cand; if (n == 0) return 0;
+    uint8_t* need = nullptr; EdgeCand* buf = nullptr; u64 cap = 1 << 16;
+    HIPCHK(hipMalloc(&need, d->N + 1)); HIPCHK(hipMemsetAsync(need, 0, d->N + 1, d->stream));
+    hipLaunchKernelGGL(k_red_mark, dim3(grid_for(n, 256)), dim3(256), 0, d->stream, d->cand, (u64)n, d->status, need);
+    // first a dry count (cap 0 keeps the flagging idempotent), then the real collection
+    HIPCHK(hipMemsetAsync(d->d_counters + 5, 0, sizeof(u64), d->stream));
+    hipLaunchKernelGGL(k_red_collect, dim3(grid_for(n, 256)), dim3(256), 0, d->stream, d->cand, (u64)n, d->status, need, (EdgeCand*)nullptr, (u64)0, d->d_counters + 5);
+    u64 cnt = 0; HIPCHK(hipMemcpyAsync(&cnt, d->d_counters + 5, sizeof cnt, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
+    if (cnt) {
+        cap = cnt; HIPCHK(hipMalloc(&buf, cap * sizeof(EdgeCand)));
+        HIPCHK(hipMemsetAsync(d->d_counters + 5, 0, sizeof(u64), d->stream));
+        hipLaunchKernelGGL(k_red_collect, dim3(grid_for(n, 256)), dim3(256), 0, d->stream, d->cand, (u64)n, d->status, need, buf, cap, d->d_counters + 5);
+        HIPCHK(hipStreamSynchronize(d->stream));
+        out.resize(cnt); HIPCHK(hipMemcpy(out.data(), buf, cnt * sizeof(EdgeCand), hipMemcpyDeviceToHost));
+        for (auto& e : out) e.type &= 0x7Fu;
+        hipFree(buf);
+    }
+    hipFree(need);
+    return 0;
+}
+int dev_unresolved_ids(Device* d, std::vector<uint32_t>& ids, std::string& err) {
+    HIPCHK(hipSetDevice(d->ordinal));
+    ids.clear(); u64 cap = 1 << 20; 
+    for (int attempt = 0; attempt < 2; attempt++) {
+        u32* buf = nullptr; HIPCHK(hipMalloc(&buf, cap * sizeof(u32)));
+        HIPCHK(hipMemsetAsync(d->d_counters + 5, 0, sizeof(u64), d->stream));
+        hipLaunchKernelGGL(k_red_unresolved, dim3(grid_for(d->N, 256)), dim3(256), 0, d->stream, (u64)d->N, d->status, buf, cap, d->d_counters + 5);
+        u64 cnt = 0; HIPCHK(hipMemcpyAsync(&cnt, d->d_counters + 5, sizeof cnt, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
+        if (cnt <= cap) { ids.resize(cnt); if (cnt) HIPCHK(hipMemcpy(ids.data(), buf, cnt * sizeof(u32), hipMemcpyDeviceToHost)); hipFree(buf); std::sort(ids.begin(), ids.end()); return 0; }
+        hipFree(buf); cap = cnt;
+    }
+    err = "unresolved id collection failed"; return SAGE2OV_ERR_INTERNAL;
+}
+
+int dev_append_edges(Device* d, const EdgeCand* e, uint64_t n, std::string& err) {
+    HIPCHK(hipSetDevice(d->ordinal));
+    if (n == 0) return 0;
+    if (d->n_cand + n > d->cand_cap) {
+        EdgeCand* nc = nullptr; u64 ncap = d->n_cand + n + 1024;
+        HIPCHK(hipMalloc(&nc, ncap * sizeof(EdgeCand)));
+        HIPCHK(hipMemcpy(nc, d->cand, d->n_cand * sizeof(EdgeCand), hipMemcpyDeviceToDevice));
+        hipFree(d->cand); d->cand = nc; d->cand_cap = ncap;
+    }
+    HIPCHK(hipMemcpy(d->cand + d->n_cand, e, n * sizeof(EdgeCand), hipMemcpyHostToDevice));
+    d->n_cand += n;
+    return 0;
+}
+
+static int scan_u32(Device* d, const u32* in, u64 n, u32* out, u64* total, std::string& err) {
+    const u64 nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    u64* partial = nullptr;
+    HIPCHK(hipMalloc(&partial, (nb + 1) * sizeof(u64)));
+    hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, d->stream, in, (u64)n, partial);
+    hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, d->stream, partial, (u64)nb, partial + nb);
+    hipLaunchKernelGGL(k_scan_final, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, d->stream, in, (u64)n, partial, out);
+    HIPCHK(hipMemcpyAsync(total, partial + nb, sizeof(u64), hipMemcpyDeviceToHost, d->stream));
+    HIPCHK(hipStreamSynchronize(d->stream));
+    hipFree(partial);
+    return 0;
+}
+
+int dev_download_edges(Device* d, std::vector<FinalEdge>& out, std::string& err) {
+    HIPCHK(hipSetDevice(d->ordinal));
+    out.resize(d->n_final);
+    if (d->n_final) HIPCHK(hipMemcpy(out.data(), d->final_edges, d->n_final * sizeof(FinalEdge), hipMemcpyDeviceToHost));
+    return 0;
+}
+int dev_convert(Device* d, uint64_t* n_final, std::string& err) {
+    HIPCHK(hipSetDevice(d->ordinal));
+    const u64 N = d->N, n = d->n_cand;
+    hipFree(d->final_edges); d->final_edges = nullptr; d->n_final = 0;
+    HIPCHK(hipEventRecord(d->ev[0], d->stream));
+    if (n) {
+        if (n >= (1ull << 32)) { err = "too many edge candidates"; return SAGE2OV_ERR_LIMIT; }
+        u32 *deg = nullptr, *offs = nullptr, *cursor = nullptr, *keep = nullptr, *pos = nullptr, *owner = nullptr; u64* keys = nullptr;
+        HIPCHK(hipMalloc(&deg, (N + 2) * sizeof(u32))); HIPCHK(hipMalloc(&offs, (N + 2) * sizeof(u32))); HIPCHK(hipMalloc(&cursor, (N + 2) * sizeof(u32)));
+        HIPCHK(hipMalloc(&keys, n * sizeof(u64))); HIPCHK(hipMalloc(&keep, n * sizeof(u32))); HIPCHK(hipMalloc(&pos, n * sizeof(u32))); HIPCHK(hipMalloc(&owner, n * sizeof(u32)));
+        HIPCHK(hipMemsetAsync(deg, 0, (N + 2) * sizeof(u32), d->stream)); HIPCHK(hipMemsetAsync(cursor, 0, (N + 2) * sizeof(u32), d->stream));
+        hipLaunchKernelGGL(k_conv_degree, dim3(grid_for(n, 256)), dim3(256), 0, d->stream, d->cand, (u64)n, deg);
+        u64 tot = 0; int rc = scan_u32(d, deg, N + 1, offs, &tot, err); if (rc) return rc;
+        hipLaunchKernelGGL(k_conv_fill, dim3(grid_for(n, 256)), dim3(256), 0, d->stream, d->cand, (u64)n, offs, cursor, keys);
+        hipLaunchKernelGGL(k_conv_sort, dim3(grid_for(N + 1, 256)), dim3(256), 0, d->stream, (u64)N, offs, deg, keys, keep);
+        hipLaunchKernelGGL(k_conv_owner, dim3(grid_for(N + 1, 256)), dim3(256), 0, d->stream, (u64)N, offs, deg, owner);
+        u64 nf = 0; rc = scan_u32(d, keep, n, pos, &nf, err); if (rc) return rc;
+        HIPCHK(hipMalloc(&d->final_edges, std::max<u64>(1, nf) * sizeof(FinalEdge)));
+        hipLaunchKernelGGL(k_conv_emit, dim3(grid_for(n, 256)), dim3(256), 0, d->stream, (u64)n, keys, keep, pos, owner, d->reads, d->S, d->final_edges);
+        d->n_final = nf;
+        HIPCHK(hipStreamSynchronize(d->stream));
+        hipFree(deg); hipFree(offs); hipFree(cursor); hipFree(keys); hipFree(keep); hipFree(pos); hipFree(owner);
+    }
+    HIPCHK(hipEventRecord(d->ev[1], d->stream));
+    HIPCHK(hipStreamSynchronize(d->stream));
+    float ms = 0; hipEventElapsedTime(&ms, d->ev[0], d->ev[1]); d->tm.convert_ms += ms;
+    *n_final = d->n_final;
+    return 0;
+}
+
+}  // namespace s2

@@ -1,0 +1,564 @@
+// sage2_amd/csrc/sage2ov_host.cpp -- host side of the C ABI (include/sage2ov.h).
+//
+// Step 1 (FASTA/FASTQ parsing, filter, canonical orientation, 2-bit packing, sort, dedupe) runs on the
+// host for now and hands the packed unique reads to HBM; steps 2-3 are HIP kernels
+// (sage2ov_device.hip).  The exact serial BFS of the reduce phase (economyGraph.cpp:513-564) is
+// replayed here from device-computed hit lists.  There is no CPU fallback for the device work.
+#include <zlib.h>
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <parallel/algorithm>
+#include <string>
+#include <unordered_map>
+#include <vector>
+#include <omp.h>
+#include "sage2ov.h"
+#include "sage2ov_internal.h"
+
+using namespace s2;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+inline uint64_t rev2_host(uint64_t x) {
+    x = ((x >> 2) & 0x3333333333333333ull) | ((x & 0x3333333333333333ull) << 2);
+    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((x & 0x0F0F0F0F0F0F0F0Full) << 4);
+    return __builtin_bswap64(x);
+}
+inline uint64_t bits64_host(const uint64_t* w, int nw, int bitpos) {
+    int q = bitpos >> 6, r = bitpos & 63;
+    uint64_t a = q < nw ? w[q] : 0;
+    if (r == 0) return a;
+    uint64_t b = q + 1 < nw ? w[q + 1] : 0;
+    return (a << r) | (b >> (64 - r));
+}
+inline uint64_t mask_top_host(int nb) { return nb >= 32 ? ~0ull : (nb <= 0 ? 0ull : (~0ull << (64 - 2 * nb))); }
+// reverse complement of an L-base word-packed read (left aligned), nw words in and out
+inline void revcomp_words(const uint64_t* in, int nw, int L, uint64_t* out) {
+    for (int c = 0; c < nw; c++) {
+        int rem = L - 32 * c; uint64_t r;
+        if (rem <= 0) r = 0;
+        else if (rem >= 32) r = ~rev2_host(bits64_host(in, nw, 2 * (rem - 32)));
+        else r = (~rev2_host(in[0] >> (64 - 2 * rem))) & mask_top_host(rem);
+        out[c] = r;
+    }
+}
+inline int flip_type_host(int t) { return t == 0 ? 3 : (t == 3 ? 0 : t); }   // utils.cpp:212
+
+struct AdjEdge { uint32_t to; uint8_t type; uint8_t mark; uint32_t len; };
+
+}  // namespace
+
+struct sage2ov_ctx {
+    sage2ov_config cfg{};
+    std::string err;
+    Device* dev = nullptr;
+    // ---- step 1 staging: variable-length word-packed canonical reads
+    std::vector<uint64_t> pool; std::vector<uint64_t> poolOff; std::vector<uint16_t> poolLen;
+    uint64_t totalReads = 0, goodReads = 0, totalBP = 0, smallReads = 0;
+    // ---- organised reads (host copy, ids 1..N)
+    uint64_t N = 0; int S = 0, maxL = 0; bool organized = false;
+    std::vector<uint64_t> words; std::vector<uint16_t> len, freq;
+    // ---- step 2/3 state
+    bool indexBuilt = false, probed = false, reciprocalDone = false, reduced = false, converted = false;
+    sage2ov_index_stats istats{};
+    sage2ov_overlap_stats ostats{};
+    std::vector<FinalEdge> edges; bool edgesOnHost = false;
+    double reduce_ms = 0, total_ms = 0;
+
+    int fail(int code, const std::string& m) { err = m; return code; }
+};
+
+namespace {
+
+// ------------------------------------------------------------------------------------------ step 1
+// filter + canonical + pack one read (readLoader.cpp:145-158, utils.cpp:144, readLoader.cpp:179-213)
+// codes: 0..3 per base or 255 for anything that is not ACGTacgt
+inline void stage_codes(sage2ov_ctx* c, const uint8_t* codes, int L, std::vector<uint64_t>& pool, std::vector<uint64_t>& off, std::vector<uint16_t>& lens,
+                        uint64_t& good, uint64_t& bp, uint64_t& small) {
+    if (L <= (int)c->cfg.min_overlap) { small++; return; }
+    const int nw = (L + 31) / 32;
+    uint64_t f[18], r[18];
+    if (nw > 16) { lens.push_back(0xFFFF); off.push_back(pool.size()); good++; bp += L; return; }   // too long: organise reports the limit
+    for (int w = 0; w < nw; w++) f[w] = 0;
+    for (int i = 0; i < L; i++) { if (codes[i] > 3) return; f[i >> 5] |= (uint64_t)codes[i] << (62 - 2 * (i & 31)); }
+    revcomp_words(f, nw, L, r);
+    bool useF = false;                                     // readLoader.cpp:195: read < revcomp ? read : revcomp
+    for (int w = 0; w < nw; w++) { if (f[w] != r[w]) { useF = f[w] < r[w]; break; } }
+    const uint64_t* src = useF ? f : r;
+    off.push_back(pool.size()); lens.push_back((uint16_t)L);
+    pool.insert(pool.end(), src, src + nw);
+    good++; bp += L;
+}
+static uint8_t g_code[256];
+struct CodeInit { CodeInit() { memset(g_code, 255, 256); g_code['A'] = g_code['a'] = 0; g_code['C'] = g_code['c'] = 1; g_code['G'] = g_code['g'] = 2; g_code['T'] = g_code['t'] = 3; } } g_code_init;
+
+// minimal FASTA/FASTQ(.gz) record reader with kseq-like rules (fastAQReader.cpp:16-45)
+struct SeqFile {
+    gzFile fp = nullptr; std::vector<char> buf; size_t pos = 0, end = 0; bool eof = false; int pending = -2;
+    bool open(const char* p) { fp = gzopen(p, "r"); buf.resize(1 << 20); return fp != nullptr; }
+    ~SeqFile() { if (fp) gzclose(fp); }
+    int getc_() { if (pos >= end) { if (eof) return -1; int n = gzread(fp, buf.data(), (unsigned)buf.size()); if (n <= 0) { eof = true; return -1; } end = n; pos = 0; } return (unsigned char)buf[pos++]; }
+    bool line(std::string& s) { s.clear(); int ch; bool any = false; while ((ch = getc_()) >= 0) { any = true; if (ch == '\n') break; s.push_back((char)ch); } if (!s.empty() && s.back() == '\r') s.pop_back(); return any; }
+    std::string held; bool haveHeld = false;
+    bool next(std::string& seq) {
+        std::string l; seq.clear();
+        for (;;) { if (haveHeld) { l = held; haveHeld = false; } else if (!line(l)) return false; if (!l.empty() && (l[0] == '>' || l[0] == '@')) break; }
+        for (;;) {
+            if (!line(l)) return true;
+            if (!l.empty() && (l[0] == '>' || l[0] == '@')) { held = l; haveHeld = true; return true; }
+            if (!l.empty() && l[0] == '+') break;
+            for (char ch : l) if (ch > ' ') seq.push_back(ch);
+        }
+        size_t q = 0; while (q < seq.size()) { if (!line(l)) break; q += l.size(); }      // quality: as many characters as bases
+        return true;
+    }
+};
+
+int add_files(sage2ov_ctx* c, const char* p1, const char* p2) {
+    SeqFile f1, f2; if (!f1.open(p1)) return c->fail(SAGE2OV_ERR_IO, std::string("cannot open ") + p1);
+    const bool two = p2 && *p2; if (two && !f2.open(p2)) return c->fail(SAGE2OV_ERR_IO, std::string("cannot open ") + p2);
+    std::string seq; std::vector<uint8_t> codes; uint64_t inFile = 0;
+    for (;;) {                                                   // inputReader.cpp:26-49: alternate by parity
+        SeqFile& f = (two && (inFile & 1)) ? f2 : f1;
+        if (!f.next(seq)) break;
+        codes.resize(seq.size());
+        for (size_t i = 0; i < seq.size(); i++) codes[i] = g_code[(unsigned char)seq[i]];
+        stage_codes(c, codes.data(), (int)seq.size(), c->pool, c->poolOff, c->poolLen, c->goodReads, c->totalBP, c->smallReads);
+        c->totalReads++; inFile++;
+    }
+    return SAGE2OV_OK;
+}
+std::string trim(const std::string& s) { size_t a = s.find_first_not_of(" \t\r\n"), b = s.find_last_not_of(" \t\r\n"); return a == std::string::npos ? "" : s.substr(a, b - a + 1); }
+
+// ------------------------------------------------------------------------------------------ reduce replay
+// exact restatement of economyGraph.cpp:495-574 over device-computed hit lists
+struct Replay {
+    sage2ov_ctx* c;
+    std::unordered_map<uint32_t, std::vector<AdjEdge>> adj;
+    std::unordered_map<uint32_t, uint8_t> st;        // unresolved reads only: 0 unexplored, 1 explored, 2 marked
+    std::unordered_map<uint32_t, std::pair<uint64_t, uint64_t>> hitRange;
+    std::unordered_map<uint32_t, uint8_t> mk;
+    const std::vector<Hit>* hits = nullptr;
+    uint64_t inserted = 0, removed = 0;
+    uint8_t status(uint32_t r) const { auto it = st.find(r); return it == st.end() ? 4 : it->second; }
+    int insert_edge(uint32_t u, uint32_t v, uint32_t delta, int type) {              // economyGraph.cpp:813-849
+        if (u == v) return 0;
+        int d2 = (int)c->len[u] - ((int)c->len[v] - (int)delta);
+        adj[u].push_back(AdjEdge{v, (uint8_t)type, 0, delta & 0xFFFFFu});
+        adj[v].push_back(AdjEdge{u, (uint8_t)flip_type_host(type), 0, (uint32_t)d2 & 0xFFFFFu});
+        return 1;
+    }
+    uint64_t explore(uint32_t r1) {                                                  // economyGraph.cpp:580-638
+        auto it = st.find(r1); if (it == st.end() || it->second != 0) return 0;
+        it->second = 1; uint64_t ins = 0;
+        auto hr = hitRange.find(r1);
+        if (hr != hitRange.end())
+            for (uint64_t x = hr->second.first; x < hr->second.second; x++) {
+                const Hit& h = (*hits)[x];
+                if (status(h.to) != 0) continue;                                     // :605 current status
+                if (h.len == -1) continue;                                           // :627 sentinel quirk
+                ins += insert_edge(r1, h.to, (uint32_t)h.len, h.type);
+            }
+        auto& a = adj[r1];
+        if (a.size() > 1) std::sort(a.begin(), a.end(), [](const AdjEdge& x, const AdjEdge& y) {   // :853-871
+            if (x.len != y.len) return x.len > y.len; if (x.to != y.to) return x.to > y.to; return x.type > y.type; });
+        return ins * 2;
+    }
+    void mark(uint32_t from) {                                                       // economyGraph.cpp:643-679
+        auto& a = adj[from];
+        for (auto& e : a) mk[e.to] = 1;
+        for (auto& e : a) {
+            if (mk[e.to] != 1) continue;
+            auto it = adj.find(e.to); if (it == adj.end()) continue;
+            for (auto& f : it->second) {
+                auto m = mk.find(f.to); if (m == mk.end() || m->second != 1) continue;
+                int t1 = e.type, t2 = f.type;
+                if ((t1 == 0 || t1 == 2) && (t2 == 0 || t2 == 1)) m->second = 2;
+                else if ((t1 == 1 || t1 == 3) && (t2 == 2 || t2 == 3)) m->second = 2;
+            }
+        }
+        for (auto& e : a) if (mk[e.to] == 2) e.mark = 1;
+        mk.clear();
+        st[from] = 2;
+    }
+    uint64_t remove_marked(uint32_t r) {                                             // economyGraph.cpp:681-707
+        auto& a = adj[r]; size_t before = a.size();
+        a.erase(std::remove_if(a.begin(), a.end(), [](const AdjEdge& e) { return e.mark != 0; }), a.end());
+        return before - a.size();
+    }
+    void run(const std::vector<uint32_t>& ids) {
+        std::vector<uint32_t> queue;
+        for (uint32_t i : ids) {
+            if (status(i) != 0) continue;
+            queue.clear(); size_t start = 0; queue.push_back(i);
+            while (start < queue.size()) {
+                uint32_t r1 = queue[start++];
+                if (status(r1) == 0) inserted += explore(r1);
+                auto it = adj.find(r1); if (it == adj.end() || it->second.empty()) continue;
+                if (status(r1) == 1) {
+                    for (size_t x = 0; x < adj[r1].size(); x++) { uint32_t r2 = adj[r1][x].to; if (status(r2) == 0) { queue.push_back(r2); inserted += explore(r2); } }
+                    mark(r1);
+                }
+                if (status(r1) == 2) {
+                    for (size_t x = 0; x < adj[r1].size(); x++) {
+                        uint32_t r2 = adj[r1][x].to; if (status(r2) != 1) continue;
+                        for (size_t y = 0; y < adj[r2].size(); y++) { uint32_t r3 = adj[r2][y].to; if (status(r3) == 0) { queue.push_back(r3); inserted += explore(r3); } }
+                        mark(r2);
+                    }
+                    removed += remove_marked(r1);
+                }
+            }
+        }
+    }
+};
+
+}  // namespace
+
+// ============================================================================================ C ABI
+extern "C" {
+
+const char* sage2ov_version(void) { return "sage2ov 0.1 (gfx950)"; }
+const char* sage2ov_last_error(const sage2ov_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+void* sage2ov_stream(sage2ov_ctx* c) { return c && c->dev ? dev_stream(c->dev) : nullptr; }
+
+int sage2ov_ctx_create(const sage2ov_config* cfg, sage2ov_ctx** out) {
+    if (!cfg || !out) { g_create_error = "null argument"; return SAGE2OV_ERR_ARG; }
+    if (cfg->min_overlap == 0) { g_create_error = "min_overlap (-k) is required"; return SAGE2OV_ERR_ARG; }   // main.cpp:506-510
+    std::string e; Device* d = nullptr;
+    if (cfg->device != SAGE2OV_DEVICE_NONE) { d = dev_create(cfg->device, e); if (!d) { g_create_error = e; return SAGE2OV_ERR_DEVICE; } }
+    auto* c = new sage2ov_ctx(); c->cfg = *cfg; c->dev = d;
+    if (c->cfg.world == 0) c->cfg.world = 1;
+    if (c->cfg.rank >= c->cfg.world) { g_create_error = "rank >= world"; if (d) dev_destroy(d); delete c; return SAGE2OV_ERR_ARG; }
+    *out = c; return SAGE2OV_OK;
+}
+void sage2ov_ctx_destroy(sage2ov_ctx* c) { if (!c) return; if (c->dev) dev_destroy(c->dev); delete c; }
+
+int sage2ov_reads_add_ascii(sage2ov_ctx* c, const char* bases, const uint64_t* off, uint64_t n) {
+    if (!c || !bases || !off) return SAGE2OV_ERR_ARG;
+    if (c->organized) return c->fail(SAGE2OV_ERR_ARG, "reads already organised");
+    std::vector<uint8_t> codes;
+    for (uint64_t r = 0; r < n; r++) {
+        const int L = (int)(off[r + 1] - off[r]); codes.resize(L);
+        for (int i = 0; i < L; i++) codes[i] = g_code[(unsigned char)bases[off[r] + i]];
+        stage_codes(c, codes.data(), L, c->pool, c->poolOff, c->poolLen, c->goodReads, c->totalBP, c->smallReads);
+        c->totalReads++;
+    }
+    return SAGE2OV_OK;
+}
+int sage2ov_reads_add_file(sage2ov_ctx* c, const char* p1, const char* p2) {
+    if (!c || !p1) return SAGE2OV_ERR_ARG;
+    if (c->organized) return c->fail(SAGE2OV_ERR_ARG, "reads already organised");
+    return add_files(c, p1, p2);
+}
+int sage2ov_reads_add_list(sage2ov_ctx* c, const char* lp) {                         // readLoader.cpp:73-131
+    if (!c || !lp) return SAGE2OV_ERR_ARG;
+    FILE* f = fopen(lp, "r"); if (!f) return c->fail(SAGE2OV_ERR_IO, std::string("cannot open ") + lp);
+    char buf[8192]; std::string val1; unsigned mate = 0; int rc = SAGE2OV_OK;
+    while (fgets(buf, sizeof buf, f)) {
+        std::string line = buf; while (!line.empty() && (line.back() == '\n' || line.back() == '\r')) line.pop_back();
+        if (line.empty() || line[0] == '#') continue;
+        size_t p = line.find('=');
+        if (p == std::string::npos) { rc = c->fail(SAGE2OV_ERR_IO, "list of input files in a wrong format"); break; }
+        std::string var = trim(line.substr(0, p)), val = trim(line.substr(p + 1));
+        if (mate % 2 == 0 && var == "f1") val1 = val;
+        else if (mate % 2 == 0 && var == "f") { rc = add_files(c, val.c_str(), nullptr); mate++; }
+        else if (mate % 2 == 1 && var == "f2") rc = add_files(c, val1.c_str(), val.c_str());
+        else { rc = c->fail(SAGE2OV_ERR_IO, "list of input files in a wrong format"); }
+        if (rc) break;
+        mate++;
+    }
+    fclose(f); return rc;
+}
+
+int sage2ov_reads_add_synth(sage2ov_ctx* c, const sage2ov_synth_params* p, const uint8_t* genome, uint64_t first, uint64_t n) {
+    if (!c || !p || !genome) return SAGE2OV_ERR_ARG;
+    if (c->organized) return c->fail(SAGE2OV_ERR_ARG, "reads already organised");
+    const int nt = c->cfg.host_threads ? (int)c->cfg.host_threads : omp_get_max_threads();
+    std::vector<std::vector<uint64_t>> pools(nt), offs(nt); std::vector<std::vector<uint16_t>> lens(nt);
+    std::vector<uint64_t> good(nt, 0), bp(nt, 0), small(nt, 0);
+    int rcAll = 0;
+    #pragma omp parallel num_threads(nt)
+    {
+        const int t = omp_get_thread_num(); const uint64_t chunk = (n + nt - 1) / nt, a = first + t * chunk, b = std::min(first + n, a + chunk);
+        std::vector<char> bases(p->read_len + 1); std::vector<uint8_t> codes(p->read_len + 1); uint64_t o[2];
+        for (uint64_t r = a; r < b; r++) {
+            int rc = sage2ov_synth_reads_ascii(p, genome, r, 1, bases.data(), o);
+            if (rc) { rcAll = rc; break; }
+            const int L = (int)o[1];
+            for (int i = 0; i < L; i++) codes[i] = g_code[(unsigned char)bases[i]];
+            stage_codes(c, codes.data(), L, pools[t], offs[t], lens[t], good[t], bp[t], small[t]);
+        }
+    }
+    if (rcAll) return c->fail(rcAll, "synthetic generator failed");
+    for (int t = 0; t < nt; t++) {                                  // concatenate in read order (thread t holds a contiguous slice)
+        const uint64_t base = c->pool.size();
+        c->pool.insert(c->pool.end(), pools[t].begin(), pools[t].end());
+        for (uint64_t o : offs[t]) c->poolOff.push_back(base + o);
+        c->poolLen.insert(c->poolLen.end(), lens[t].begin(), lens[t].end());
+        c->goodReads += good[t]; c->totalBP += bp[t]; c->smallReads += small[t];
+    }
+    c->totalReads += n;
+    return SAGE2OV_OK;
+}
+
+static int upload(sage2ov_ctx* c) {
+    if (!c->dev) { c->organized = true; return SAGE2OV_OK; }      // step-1-only context (SAGE2OV_DEVICE_NONE)
+    int rc = dev_upload_reads(c->dev, c->words.data(), c->N, c->S, c->maxL, (int)c->cfg.min_overlap, c->err);
+    if (rc) return rc;
+    c->organized = true; c->indexBuilt = c->probed = c->reciprocalDone = c->reduced = c->converted = false;
+    return SAGE2OV_OK;
+}
+static int choose_S(int maxL) { int need = (2 * maxL + 16 + 63) / 64; int S = 4; while (S < need) S *= 2; return S; }
+
+int sage2ov_reads_organize(sage2ov_ctx* c) {                                          // readLoader.cpp:215-260
+    if (!c) return SAGE2OV_ERR_ARG;
+    if (c->organized) return c->fail(SAGE2OV_ERR_ARG, "reads already organised");
+    if (c->cfg.host_threads) omp_set_num_threads((int)c->cfg.host_threads);
+    const uint64_t n = c->poolLen.size();
+    int maxL = 0; for (uint64_t i = 0; i < n; i++) maxL = std::max<int>(maxL, c->poolLen[i]);
+    c->maxL = maxL; c->S = choose_S(std::max(maxL, 1));
+    if (c->S > 16 || maxL > 504) return c->fail(SAGE2OV_ERR_LIMIT, "reads longer than 504 bases are not supported");
+    if (n >= (1ull << 32)) return c->fail(SAGE2OV_ERR_LIMIT, "too many reads for the host organiser");
+    std::vector<uint32_t> ord(n);
+    #pragma omp parallel for
+    for (uint64_t i = 0; i < n; i++) ord[i] = (uint32_t)i;
+    const uint64_t* pool = c->pool.data(); const uint64_t* off = c->poolOff.data(); const uint16_t* pl = c->poolLen.data();
+    auto cmp = [&](uint32_t a, uint32_t b) -> int {                                   // utils.cpp:224-242 on big-endian words
+        const int la = pl[a], lb = pl[b], wa = (la + 31) / 32, wb = (lb + 31) / 32, wm = std::min(wa, wb);
+        const uint64_t *pa = pool + off[a], *pb = pool + off[b];
+        for (int w = 0; w < wm; w++) { if (pa[w] != pb[w]) return pa[w] < pb[w] ? -1 : 1; }
+        // bytes beyond the shorter read's last WORD may still be inside its last byte range: the reference compares
+        // ceil(len/4) bytes, all of which lie in the first wm words except when the longer read has more words;
+        // those extra bytes only matter while they are within min(bytes): they are not (min bytes <= 8*wm).
+        if (la != lb) {
+            // the shorter read is zero padded inside its last word, so a difference within min(bytes) was caught above
+            return la < lb ? -1 : 1;
+        }
+        return 0;
+    };
+    __gnu_parallel::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return cmp(a, b) < 0; });   // readLoader.cpp:221
+    // unique + frequency (readLoader.cpp:225-235)
+    std::vector<uint32_t> firstOf; firstOf.reserve(n); std::vector<uint16_t> fr; fr.reserve(n);
+    for (uint64_t x = 0; x < n; x++) {
+        if (x == 0 || cmp(ord[x - 1], ord[x]) != 0) { firstOf.push_back(ord[x]); fr.push_back(0); }
+        fr.back()++;                                                                  // u16 wrap like the reference
+    }
+    const uint64_t N = firstOf.size(); const int S = c->S;
+    c->N = N; c->words.assign((N + 1) * S, 0); c->len.assign(N + 1, 0); c->freq.assign(N + 1, 0);
+    #pragma omp parallel for
+    for (uint64_t i = 1; i <= N; i++) {
+        const uint32_t a = firstOf[i - 1]; const int L = pl[a], nw = (L + 31) / 32;
+        uint64_t* w = &c->words[i * S];
+        for (int q = 0; q < nw; q++) w[q] = pool[off[a] + q];
+        w[S - 1] |= (uint64_t)L;                                                       // length in the low 16 bits of the last word
+        c->len[i] = (uint16_t)L; c->freq[i] = fr[i - 1];
+    }
+    std::vector<uint64_t>().swap(c->pool); std::vector<uint64_t>().swap(c->poolOff); std::vector<uint16_t>().swap(c->poolLen);
+    return upload(c);
+}
+
+int sage2ov_reads_stats(const sage2ov_ctx* c, sage2ov_read_stats* o) {
+    if (!c || !o) return SAGE2OV_ERR_ARG;
+    o->total_reads = c->totalReads; o->good_reads = c->goodReads; o->unique_reads = c->N; o->total_bp = c->totalBP;
+    o->average_read_length = c->goodReads ? c->totalBP / c->goodReads : 0; o->max_read_length = (uint32_t)c->maxL; o->words_per_read = (uint32_t)c->S;
+    return SAGE2OV_OK;
+}
+static void unpack_bytes(const uint64_t* w, int L, uint8_t* out, uint64_t stride) {    // word image -> utils.cpp:96 byte image
+    const int nb = (L + 3) / 4; for (uint64_t b = 0; b < stride; b++) out[b] = 0;
+    for (int b = 0; b < nb && (uint64_t)b < stride; b++) out[b] = (uint8_t)(w[b >> 3] >> (56 - 8 * (b & 7)));
+    if (L & 3) out[nb - 1] &= (uint8_t)(0xFF << (8 - 2 * (L & 3)));
+}
+int sage2ov_reads_export(const sage2ov_ctx* c, uint8_t* packed, uint64_t stride, uint16_t* length, uint16_t* frequency) {
+    if (!c || !c->organized) return SAGE2OV_ERR_ARG;
+    for (uint64_t i = 0; i <= c->N; i++) {
+        if (packed) { if (i == 0) memset(packed, 0, stride); else unpack_bytes(&c->words[i * c->S], c->len[i], packed + i * stride, stride); }
+        if (length) length[i] = c->len[i];
+        if (frequency) frequency[i] = c->freq[i];
+    }
+    return SAGE2OV_OK;
+}
+static void words_to_ascii(const uint64_t* w, int L, char* out) { static const char B[4] = {'A', 'C', 'G', 'T'}; for (int i = 0; i < L; i++) out[i] = B[(w[i >> 5] >> (62 - 2 * (i & 31))) & 3]; }
+int sage2ov_reads_save(sage2ov_ctx* c, const char* path) {                            // readLoader.cpp:270-287, :29-36
+    if (!c || !path || !c->organized) return SAGE2OV_ERR_ARG;
+    FILE* f = fopen(path, "w"); if (!f) return c->fail(SAGE2OV_ERR_IO, std::string("cannot open ") + path);
+    std::vector<char> io(1 << 22); setvbuf(f, io.data(), _IOFBF, io.size());
+    fprintf(f, "%llu\n", (unsigned long long)c->N);
+    std::vector<char> a(c->maxL + 1), b(c->maxL + 1); uint64_t r[18];
+    for (uint64_t i = 1; i <= c->N; i++) {
+        const int L = c->len[i]; const uint64_t* w = &c->words[i * c->S];
+        uint64_t tmp[18]; const int nw = (L + 31) / 32; for (int q = 0; q < nw; q++) tmp[q] = w[q]; if (nw == c->S) tmp[nw - 1] &= ~0xFFFFull;
+        words_to_ascii(tmp, L, a.data()); revcomp_words(tmp, nw, L, r); words_to_ascii(r, L, b.data());
+        fprintf(f, "%u\t%u\t%.*s\t%.*s\n", (unsigned)c->freq[i], (unsigned)L, L, a.data(), L, b.data());
+    }
+    fclose(f); return SAGE2OV_OK;
+}
+int sage2ov_reads_load(sage2ov_ctx* c, const char* path) {                            // readLoader.cpp:289-307, :38-48
+    if (!c || !path) return SAGE2OV_ERR_ARG;
+    FILE* f = fopen(path, "r"); if (!f) return c->fail(SAGE2OV_ERR_IO, std::string("cannot open ") + path);
+    unsigned long long N = 0; if (fscanf(f, "%llu", &N) != 1) { fclose(f); return c->fail(SAGE2OV_ERR_IO, "bad .reads header"); }
+    std::vector<std::string> seqs(N + 1); std::vector<unsigned> fr(N + 1), ln(N + 1); int maxL = 0;
+    std::vector<char> a(70000), b(70000);
+    for (unsigned long long i = 1; i <= N; i++) {
+        if (fscanf(f, "%u %u %69999s %69999s", &fr[i], &ln[i], a.data(), b.data()) != 4) { fclose(f); return c->fail(SAGE2OV_ERR_IO, "bad .reads record"); }
+        seqs[i] = a.data(); maxL = std::max<int>(maxL, (int)ln[i]);
+    }
+    fclose(f);
+    c->maxL = maxL; c->S = choose_S(std::max(maxL, 1)); if (c->S > 16) return c->fail(SAGE2OV_ERR_LIMIT, "reads longer than 504 bases are not supported");
+    c->N = N; const int S = c->S; c->words.assign((N + 1) * S, 0); c->len.assign(N + 1, 0); c->freq.assign(N + 1, 0);
+    for (unsigned long long i = 1; i <= N; i++) {
+        const int L = (int)ln[i]; uint64_t* w = &c->words[i * S];
+        for (int p = 0; p < L && p < (int)seqs[i].size(); p++) { uint8_t x = g_code[(unsigned char)seqs[i][p]]; if (x > 3) x = 0; w[p >> 5] |= (uint64_t)x << (62 - 2 * (p & 31)); }
+        w[S - 1] |= (uint64_t)L; c->len[i] = (uint16_t)L; c->freq[i] = (uint16_t)fr[i];
+    }
+    c->organized = false;
+    return upload(c);
+}
+int sage2ov_reads_set_totals(sage2ov_ctx* c, uint64_t good, uint64_t bp) { if (!c) return SAGE2OV_ERR_ARG; c->goodReads = good; c->totalBP = bp; return SAGE2OV_OK; }
+
+// ------------------------------------------------------------------------------------------ step 2
+int sage2ov_index_build(sage2ov_ctx* c) {
+    if (!c) return SAGE2OV_ERR_ARG;
+    if (!c->dev) return c->fail(SAGE2OV_ERR_DEVICE, "this context has no GPU (SAGE2OV_DEVICE_NONE): steps 2-3 are device-only");
+    if (!c->organized) return c->fail(SAGE2OV_ERR_ARG, "organise (or load) the reads first");
+    uint64_t slots, keys, csr, nlong; uint32_t reb;
+    int rc = dev_build_index(c->dev, &slots, &keys, &csr, &nlong, &reb, c->err); if (rc) return rc;
+    c->istats.slots = slots; c->istats.keys = keys; c->istats.csr_entries = csr; c->istats.long_buckets = nlong;
+    c->istats.hash_string_length = c->cfg.min_overlap > 64 ? 64 : c->cfg.min_overlap; c->istats.rebuilds = reb;
+    c->indexBuilt = true; c->probed = c->reciprocalDone = c->reduced = c->converted = false;
+    return SAGE2OV_OK;
+}
+int sage2ov_index_stats_get(const sage2ov_ctx* c, sage2ov_index_stats* o) { if (!c || !o) return SAGE2OV_ERR_ARG; *o = c->istats; return SAGE2OV_OK; }
+int sage2ov_index_lookup(sage2ov_ctx* c, const uint64_t key[2], uint64_t* entries, uint32_t cap, uint32_t* count) {
+    if (!c || !key || !count) return SAGE2OV_ERR_ARG;
+    if (!c->indexBuilt) return c->fail(SAGE2OV_ERR_ARG, "index not built");
+    return dev_lookup(c->dev, key[0], key[1], entries, cap, count, c->err);
+}
+
+// ------------------------------------------------------------------------------------------ step 3
+int sage2ov_shard_range(const sage2ov_ctx* c, uint64_t* lo, uint64_t* hi) {
+    if (!c || !lo || !hi) return SAGE2OV_ERR_ARG;
+    const uint64_t N = c->N, w = c->cfg.world, r = c->cfg.rank;
+    *lo = 1 + (N * r) / w; *hi = 1 + (N * (r + 1)) / w; return SAGE2OV_OK;
+}
+int sage2ov_shard_record_bytes(const sage2ov_ctx* c, uint64_t* b) { if (!c || !b) return SAGE2OV_ERR_ARG; *b = 24; return SAGE2OV_OK; }
+int sage2ov_overlap_probe_shard(sage2ov_ctx* c) {
+    if (!c) return SAGE2OV_ERR_ARG;
+    if (!c->indexBuilt) return c->fail(SAGE2OV_ERR_ARG, "build the index first");
+    uint64_t lo, hi; sage2ov_shard_range(c, &lo, &hi);
+    int rc = dev_probe(c->dev, lo, hi, c->err); if (rc) return rc;
+    c->probed = true; c->reciprocalDone = c->reduced = c->converted = false; return SAGE2OV_OK;
+}
+int sage2ov_shard_export_records(sage2ov_ctx* c, void* dst, uint64_t max_reads) {
+    if (!c || !dst) return SAGE2OV_ERR_ARG; if (!c->probed) return c->fail(SAGE2OV_ERR_ARG, "probe first");
+    uint64_t lo, hi; sage2ov_shard_range(c, &lo, &hi); if (hi - lo > max_reads) return c->fail(SAGE2OV_ERR_ARG, "destination too small");
+    return dev_export_records(c->dev, dst, lo, hi, c->err);
+}
+int sage2ov_shard_import_records(sage2ov_ctx* c, const void* src, uint64_t first, uint64_t n) {
+    if (!c || !src) return SAGE2OV_ERR_ARG; if (first < 1 || first + n > c->N + 1) return c->fail(SAGE2OV_ERR_ARG, "id range out of bounds");
+    return dev_import_records(c->dev, src, first, n, c->err);
+}
+int sage2ov_overlap_reciprocal(sage2ov_ctx* c) {
+    if (!c) return SAGE2OV_ERR_ARG; if (!c->probed) return c->fail(SAGE2OV_ERR_ARG, "probe first");
+    uint64_t nov, cont, csize; int rc = dev_reciprocal(c->dev, &nov, &cont, &csize, c->err); if (rc) return rc;
+    c->ostats = sage2ov_overlap_stats{}; c->ostats.verified_overlaps = nov; c->ostats.contained_extension = cont; c->ostats.contained_size = csize;
+    c->ostats.left_to_explore = c->N - cont - csize;
+    c->reciprocalDone = true; c->reduced = c->converted = false; return SAGE2OV_OK;
+}
+int sage2ov_overlap_initial(sage2ov_ctx* c) {
+    if (!c) return SAGE2OV_ERR_ARG;
+    if (c->cfg.world > 1) return c->fail(SAGE2OV_ERR_ARG, "multi-GPU contexts use probe_shard / export / import / reciprocal");
+    int rc = sage2ov_overlap_probe_shard(c); if (rc) return rc;
+    return sage2ov_overlap_reciprocal(c);
+}
+
+int sage2ov_overlap_reduce(sage2ov_ctx* c) {
+    if (!c) return SAGE2OV_ERR_ARG; if (!c->reciprocalDone) return c->fail(SAGE2OV_ERR_ARG, "run the initial pass first");
+    auto t0 = std::chrono::steady_clock::now();
+    std::vector<Hit> hits; uint64_t nun = 0;
+    int rc = dev_unresolved_hits(c->dev, hits, &nun, c->err); if (rc) return rc;
+    c->ostats.unresolved_hits = hits.size(); c->ostats.edges_inserted = 0; c->ostats.transitive_removed = 0;
+    if (nun) {
+        std::vector<uint32_t> ids; rc = dev_unresolved_ids(c->dev, ids, c->err); if (rc) return rc;
+        std::vector<EdgeCand> near; rc = dev_collect_reduce_edges(c->dev, near, c->err); if (rc) return rc;
+        __gnu_parallel::sort(hits.begin(), hits.end(), [](const Hit& a, const Hit& b) { return a.from != b.from ? a.from < b.from : a.seq < b.seq; });
+        Replay R; R.c = c; R.hits = &hits;
+        R.st.reserve(ids.size() * 2); for (uint32_t i : ids) R.st[i] = 0;
+        for (uint64_t x = 0; x < hits.size();) { uint64_t y = x; while (y < hits.size() && hits[y].from == hits[x].from) y++; R.hitRange[hits[x].from] = {x, y}; x = y; }
+        for (auto& e : near) {                                                        // both directed entries of every stored edge
+            R.adj[e.from].push_back(AdjEdge{e.to, (uint8_t)e.type, 0, e.len});
+            int d2 = (int)c->len[e.from] - ((int)c->len[e.to] - (int)e.len);         // twin length, economyGraph.cpp:821 applied to the twin
+            // e is the entry of list[from]; it was created either directly (u=from) or as the twin of (u=to): either way the
+            // other list holds the involutive twin
+            R.adj[e.to].push_back(AdjEdge{e.from, (uint8_t)flip_type_host(e.type), 0, (uint32_t)((int)c->len[e.to] - ((int)c->len[e.from] - (int)e.len)) & 0xFFFFFu});
+            (void)d2;
+        }
+        R.run(ids);
+        c->ostats.edges_inserted = R.inserted; c->ostats.transitive_removed = R.removed;
+        // surviving list entries of unresolved reads with to > from replace what the device dropped
+        std::vector<EdgeCand> survivors;
+        for (uint32_t i : ids) { auto it = R.adj.find(i); if (it == R.adj.end()) continue; for (auto& e : it->second) if (e.to > i) survivors.push_back(EdgeCand{i, e.to, e.len, e.type}); }
+        rc = dev_append_edges(c->dev, survivors.data(), survivors.size(), c->err); if (rc) return rc;
+    }
+    c->reduce_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    c->reduced = true; c->converted = false; return SAGE2OV_OK;
+}
+
+int sage2ov_overlap_convert(sage2ov_ctx* c) {
+    if (!c) return SAGE2OV_ERR_ARG; if (!c->reduced) return c->fail(SAGE2OV_ERR_ARG, "run the reduce phase first");
+    uint64_t nf = 0; int rc = dev_convert(c->dev, &nf, c->err); if (rc) return rc;
+    c->ostats.edges = nf; c->edgesOnHost = false; c->converted = true; return SAGE2OV_OK;
+}
+int sage2ov_overlap_stats_get(const sage2ov_ctx* c, sage2ov_overlap_stats* o) { if (!c || !o) return SAGE2OV_ERR_ARG; *o = c->ostats; return SAGE2OV_OK; }
+int sage2ov_overlap_export_initial(sage2ov_ctx* c, uint64_t* r, uint64_t* l, uint8_t* st, uint32_t* cn) {
+    if (!c) return SAGE2OV_ERR_ARG; if (!c->reciprocalDone) return c->fail(SAGE2OV_ERR_ARG, "run the initial pass first");
+    return dev_download_initial(c->dev, r, l, st, cn, c->err);
+}
+static int fetch_edges(sage2ov_ctx* c) {
+    if (!c->converted) return c->fail(SAGE2OV_ERR_ARG, "run convert first");
+    if (c->edgesOnHost) return SAGE2OV_OK;
+    int rc = dev_download_edges(c->dev, c->edges, c->err); if (rc) return rc;
+    c->edgesOnHost = true; return SAGE2OV_OK;
+}
+int sage2ov_edges_count(const sage2ov_ctx* c, uint64_t* n) { if (!c || !n || !c->converted) return SAGE2OV_ERR_ARG; *n = c->ostats.edges; return SAGE2OV_OK; }
+int sage2ov_edges_export(sage2ov_ctx* c, sage2ov_edge* out, uint64_t cap) {
+    if (!c || !out) return SAGE2OV_ERR_ARG; int rc = fetch_edges(c); if (rc) return rc;
+    if (cap < c->edges.size()) return c->fail(SAGE2OV_ERR_ARG, "edge buffer too small");
+    for (size_t x = 0; x < c->edges.size(); x++) { const FinalEdge& e = c->edges[x]; sage2ov_edge o{}; o.from = e.from; o.to = e.to; o.length = e.len; o.length_twin = e.len_twin; o.type = (uint8_t)e.type; out[x] = o; }
+    return SAGE2OV_OK;
+}
+int sage2ov_graph_save(sage2ov_ctx* c, const char* path) {                            // overlapGraph.cpp:338-369, :12-20
+    if (!c || !path) return SAGE2OV_ERR_ARG; int rc = fetch_edges(c); if (rc) return rc;
+    FILE* f = fopen(path, "w"); if (!f) return c->fail(SAGE2OV_ERR_IO, std::string("cannot open ") + path);
+    std::vector<char> io(1 << 22); setvbuf(f, io.data(), _IOFBF, io.size());
+    fprintf(f, "0\n%llu\n%llu\n", (unsigned long long)c->goodReads, (unsigned long long)(c->goodReads ? c->totalBP / c->goodReads : 0));
+    for (const FinalEdge& e : c->edges) {
+        fprintf(f, "%u\t%u\t%u\t1\t%u\t0\t0\n\n", e.from, e.to, e.type, e.len);
+        fprintf(f, "%u\t%u\t%u\t1\t%u\t0\t0\n\n", e.to, e.from, (unsigned)flip_type_host((int)e.type), e.len_twin);
+    }
+    fclose(f); return SAGE2OV_OK;
+}
+
+int sage2ov_run_steps23(sage2ov_ctx* c) {
+    if (!c) return SAGE2OV_ERR_ARG;
+    auto t0 = std::chrono::steady_clock::now();
+    if (c->dev) dev_reset_timings(c->dev);
+    int rc = sage2ov_index_build(c); if (rc) return rc;
+    rc = sage2ov_overlap_initial(c); if (rc) return rc;
+    rc = sage2ov_overlap_reduce(c); if (rc) return rc;
+    rc = sage2ov_overlap_convert(c); if (rc) return rc;
+    c->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return SAGE2OV_OK;
+}
+int sage2ov_timings_get(const sage2ov_ctx* c, sage2ov_timings* o) {
+    if (!c || !o) return SAGE2OV_ERR_ARG;
+    DevTimings t; if (c->dev) dev_timings(c->dev, &t);
+    o->index_ms = t.index_ms; o->probe_ms = t.probe_ms; o->reciprocal_ms = t.reciprocal_ms; o->reduce_ms = c->reduce_ms; o->convert_ms = t.convert_ms;
+    o->total_ms = c->total_ms; o->probe_kernel_ms = t.probe_kernel_ms; o->probe_kernel_launches = t.probe_launches;
+    return SAGE2OV_OK;
+}
+
+}  // extern "C"

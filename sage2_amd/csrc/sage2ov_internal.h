@@ -1,0 +1,67 @@
+// sage2_amd/csrc/sage2ov_internal.h -- interface between the host side (sage2ov_host.cpp, g++)
+// and the device side (sage2ov_device.hip, hipcc).  Plain C++ structs, no HIP types leak out.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace s2 {
+
+// ----------------------------------------------------------------------------------------------
+// HBM layout of the read store
+//   reads: (N+1) slots of S u64 words (S = 4, 8 or 16: a power of two so a read never straddles a
+//   64-byte sector boundary more than its size requires).  Base p of a read lives in word p/32 at
+//   bits 63-2(p%32)..62-2(p%32) (A0 C1 G2 T3): the byte-swapped image of the reference's MSB-first
+//   byte packing (utils.cpp:96), so unsigned word compare == the reference's byte compare.
+//   The read length sits in the low 16 bits of the slot's last word (bases never reach there:
+//   S is chosen with 2*maxL + 16 <= 64*S).  Slot 0 is all zero (ids are 1-based).
+// Index slot (8 bytes):  tag:24 | cnt:7 | payload:33
+//   0 = empty; cnt 1 -> payload is the single entry id*4+type; 2..99 -> payload = offset into csr[];
+//   127 -> long bucket (>= 100 entries, hashTable.cpp:111-123): never matches a lookup.
+// ----------------------------------------------------------------------------------------------
+constexpr uint64_t SLOT_TAG_SHIFT = 40;
+constexpr uint64_t SLOT_CNT_SHIFT = 33;
+constexpr uint64_t SLOT_PAY_MASK = (1ull << 33) - 1;
+constexpr uint32_t SLOT_CNT_LONG = 127;
+constexpr uint32_t HASH_THRESHOLD = 100;   // hashTable.cpp:76
+constexpr uint32_t CONN_LIMIT = 300;       // economyGraph.cpp:43
+
+struct EdgeCand { uint32_t from, to; uint32_t len; uint32_t type; };   // from < to, len already 20-bit masked
+struct Hit { uint32_t from; uint32_t to; int32_t len; uint16_t seq_hi; uint8_t type; uint8_t pad; uint32_t seq; };
+struct FinalEdge { uint32_t from, to, len, len_twin; uint32_t type; };
+
+struct DevTimings { double index_ms = 0, probe_ms = 0, reciprocal_ms = 0, hits_ms = 0, convert_ms = 0, probe_kernel_ms = 0; uint64_t probe_launches = 0; };
+
+struct Device;   // opaque, lives in sage2ov_device.hip
+
+// every function returns 0 on success, else a negative SAGE2OV_ERR_* and fills err
+Device* dev_create(int device_ordinal, std::string& err);
+void dev_destroy(Device* d);
+void* dev_stream(Device* d);
+
+int dev_upload_reads(Device* d, const uint64_t* words, uint64_t N, int S, int maxL, int k, std::string& err);
+int dev_build_index(Device* d, uint64_t* slots, uint64_t* keys, uint64_t* csr, uint64_t* nlong, uint32_t* rebuilds, std::string& err);
+int dev_lookup(Device* d, uint64_t hi, uint64_t lo, uint64_t* entries, uint32_t cap, uint32_t* count, std::string& err);
+// probe+verify+extension kernel over ids [lo, hi)
+int dev_probe(Device* d, uint64_t lo, uint64_t hi, std::string& err);
+// multi-GPU record exchange: 24 bytes per read {right u64, left u64, conn u32, cflag u32}
+int dev_export_records(Device* d, void* dev_dst, uint64_t lo, uint64_t hi, std::string& err);
+int dev_import_records(Device* d, const void* dev_src, uint64_t first, uint64_t n, std::string& err);
+// reciprocal pass (economyGraph.cpp:455-480) over all reads -> status[], edge candidates on device
+int dev_reciprocal(Device* d, uint64_t* n_ov, uint64_t* contained, uint64_t* contained_size, std::string& err);
+int dev_download_initial(Device* d, uint64_t* right, uint64_t* left, uint8_t* status, uint32_t* conn, std::string& err);
+// directional hit lists of status-0 reads (economyGraph.cpp:591-633), sorted by (from, seq)
+int dev_unresolved_hits(Device* d, std::vector<Hit>& hits, uint64_t* n_unresolved, std::string& err);
+int dev_download_status(Device* d, std::vector<uint8_t>& status, std::string& err);
+int dev_unresolved_ids(Device* d, std::vector<uint32_t>& ids, std::string& err);          // ascending
+int dev_collect_reduce_edges(Device* d, std::vector<EdgeCand>& out, std::string& err);
+// append host-computed edge candidates (from the reduce replay) to the device candidate list
+int dev_append_edges(Device* d, const EdgeCand* e, uint64_t n, std::string& err);
+// sortEconomyGraph + convertGraph: canonical list
+int dev_convert(Device* d, uint64_t* n_final, std::string& err);     // result stays in HBM
+int dev_download_edges(Device* d, std::vector<FinalEdge>& out, std::string& err);
+void dev_timings(Device* d, DevTimings* t);
+void dev_reset_timings(Device* d);
+int dev_sync(Device* d, std::string& err);
+
+}  // namespace s2

@@ -1,0 +1,86 @@
+"""CPU: the C-ABI library loads and exports every symbol include/sage2ov.h declares; the step-1 host
+path (which needs no GPU) reproduces the reference's P.reads; compute calls fail loudly without a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import fixtures as fx
+import sage2_amd as s2
+
+HEADER = os.path.join(fx.ROOT, "include", "sage2ov.h")
+
+
+def declared_symbols():
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(sage2ov_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = s2.lib()
+    syms = declared_symbols()
+    assert len(syms) >= 35
+    for s in syms:
+        assert hasattr(L, s), f"{s} declared in sage2ov.h but not exported"
+    assert b"gfx950" in L.sage2ov_version()
+
+
+def test_step1_host_path_reproduces_reference_reads_file(tmp_path):
+    for name in ("g1_clean100_k21", "g5_mixedlen_k21", "g6_k70_150"):
+        m = fx.golden(name)
+        bases, off = fx.make_reads(m["synth"])
+        ctx = s2.Context(m["k"], device=-2)            # SAGE2OV_DEVICE_NONE: step 1 only
+        ctx.reads_add_ascii(bases, off)
+        ctx.reads_organize()
+        st = ctx.reads_stats()
+        assert st.unique_reads == m["counters"]["unique_reads"] and st.good_reads == m["counters"]["good_reads"]
+        p = str(tmp_path / (name + ".reads"))
+        ctx.reads_save(p)
+        assert fx.md5_file(p) == m["reads_md5"]
+        ctx.close()
+
+
+def test_fasta_reader_and_synth_paths_agree(tmp_path):
+    m = fx.golden("g2_clean150_k40")
+    p = fx.synth_params(m["synth"])
+    fa = str(tmp_path / "x.fa")
+    s2.synth_write_fasta(p, fa)
+    assert fx.md5_file(fa) == m["fasta_md5"]
+    a = s2.Context(m["k"], device=-2); a.reads_add_file(fa); a.reads_organize()
+    b = s2.Context(m["k"], device=-2); b.reads_add_synth(p, s2.synth_genome(p)); b.reads_organize()
+    pa, la, fa_ = a.reads_export(); pb, lb, fb = b.reads_export()
+    assert np.array_equal(pa, pb) and np.array_equal(la, lb) and np.array_equal(fa_, fb)
+    # a list file (readLoader.cpp:86-118) with split mates gives the same set
+    f1, f2 = str(tmp_path / "m1.fa"), str(tmp_path / "m2.fa")
+    with open(fa) as f, open(f1, "w") as o1, open(f2, "w") as o2:
+        lines = f.read().splitlines()
+        for r in range(0, len(lines), 2):
+            (o1 if (r // 2) % 2 == 0 else o2).write(lines[r] + "\n" + lines[r + 1] + "\n")
+    lst = str(tmp_path / "in.list")
+    open(lst, "w").write(f"# comment\nf1={f1}\nf2={f2}\n")
+    c = s2.Context(m["k"], device=-2); c.reads_add_list(lst); c.reads_organize()
+    pc, lc, fc = c.reads_export()
+    assert np.array_equal(pa, pc) and np.array_equal(fa_, fc)
+    for x in (a, b, c):
+        x.close()
+
+
+def test_filters_and_errors():
+    ctx = s2.Context(5, device=-2)
+    reads = [b"ACGTAC", b"ACGTN", b"ACGT", b"acgtacgt", b"GTACGT"]   # N -> bad; len<=k -> small; lower case folded
+    bases = np.frombuffer(b"".join(reads), dtype=np.uint8)
+    off = np.cumsum([0] + [len(r) for r in reads]).astype(np.uint64)
+    ctx.reads_add_ascii(bases, off)
+    ctx.reads_organize()
+    st = ctx.reads_stats()
+    assert (st.total_reads, st.good_reads) == (5, 3)
+    assert st.unique_reads == 2            # ACGTAC and GTACGT are reverse complements of each other
+    with pytest.raises(s2.Sage2ovError) as e:
+        ctx.index_build()
+    assert e.value.code == -3              # SAGE2OV_ERR_DEVICE: no silent CPU fallback
+    ctx.close()
+    with pytest.raises(s2.Sage2ovError):
+        s2.Context(0, device=-2)           # -k is required (main.cpp:506-510)
