@@ -921,9 +921,13 @@ int dev_convert(Device* d, uint64_t* n_final, std::string& err) {
         hipLaunchKernelGGL(k_conv_fill, dim3(grid_for(n, 256)), dim3(256), 0, d->stream, d->cand, (u64)n, offs, cursor, keys);
         hipLaunchKernelGGL(k_conv_sort, dim3(grid_for(N + 1, 256)), dim3(256), 0, d->stream, (u64)N, offs, deg, keys, keep);
         hipLaunchKernelGGL(k_conv_owner, dim3(grid_for(N + 1, 256)), dim3(256), 0, d->stream, (u64)N, offs, deg, owner);
-        u64 nf = 0; rc = scan_u32(d, keep, n, pos, &nf, err); if (rc) return rc;
-        HIPCHK(hipMalloc(&d->final_edges, std::max<u64>(1, nf) * sizeof(FinalEdge)));
-        hipLaunchKernelGGL(k_conv_emit, dim3(grid_for(n, 256)), dim3(256), 0, d->stream, (u64)n, keys, keep, pos, owner, d->reads, d->S, d->final_edges);
+        // `tot` = candidates still alive (dropped ones were never filled in): only keys[0..tot) are defined
+        u64 nf = 0;
+        if (tot) {
+            rc = scan_u32(d, keep, tot, pos, &nf, err); if (rc) return rc;
+            HIPCHK(hipMalloc(&d->final_edges, std::max<u64>(1, nf) * sizeof(FinalEdge)));
+            hipLaunchKernelGGL(k_conv_emit, dim3(grid_for(tot, 256)), dim3(256), 0, d->stream, (u64)tot, keys, keep, pos, owner, d->reads, d->S, d->final_edges);
+        }
         d->n_final = nf;
         HIPCHK(hipStreamSynchronize(d->stream));
         hipFree(deg); hipFree(offs); hipFree(cursor); hipFree(keys); hipFree(keep); hipFree(pos); hipFree(owner);

@@ -490,11 +490,10 @@ int sage2ov_overlap_reduce(sage2ov_ctx* c) {
         for (uint64_t x = 0; x < hits.size();) { uint64_t y = x; while (y < hits.size() && hits[y].from == hits[x].from) y++; R.hitRange[hits[x].from] = {x, y}; x = y; }
         for (auto& e : near) {                                                        // both directed entries of every stored edge
             R.adj[e.from].push_back(AdjEdge{e.to, (uint8_t)e.type, 0, e.len});
-            int d2 = (int)c->len[e.from] - ((int)c->len[e.to] - (int)e.len);         // twin length, economyGraph.cpp:821 applied to the twin
-            // e is the entry of list[from]; it was created either directly (u=from) or as the twin of (u=to): either way the
-            // other list holds the involutive twin
-            R.adj[e.to].push_back(AdjEdge{e.from, (uint8_t)flip_type_host(e.type), 0, (uint32_t)((int)c->len[e.to] - ((int)c->len[e.from] - (int)e.len)) & 0xFFFFFu});
-            (void)d2;
+            // e is the entry of list[from]; it was created either directly (u=from) or as the twin of (u=to): either way
+            // list[to] holds the involutive twin, length L_from - (L_to - len)  (economyGraph.cpp:821)
+            const int d2 = (int)c->len[e.from] - ((int)c->len[e.to] - (int)e.len);
+            R.adj[e.to].push_back(AdjEdge{e.from, (uint8_t)flip_type_host(e.type), 0, (uint32_t)d2 & 0xFFFFFu});
         }
         R.run(ids);
         c->ostats.edges_inserted = R.inserted; c->ostats.transitive_removed = R.removed;
