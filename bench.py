@@ -1,0 +1,247 @@
+#!/usr/bin/env python3
+"""bench.py -- overlaps/sec of the MI355X-native SAGE2 read-overlap path (steps 2-3) on synthetic paired-end reads.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 launched through
+torch.distributed.run, one rank per GPU.  One "step" = one pass of the hot path over the resident read set:
+index build + initial pass (probe/verify/extension + reciprocal) + reduce + sort/convert, i.e. the timed
+region T of SURVEY.md 8(d) ("packed unique reads resident in HBM" -> "canonical edge list resident").
+value = N_ov / T, N_ov = verified suffix-prefix overlaps (sum of the reference's `connections`).
+Workload at N=1: BASELINE.json configs[1] (10 M x 150 bp, k=40, 30 Mb genome, seed 2).  N>1: the same read set,
+read ids range-partitioned over the ranks (strong scaling), records/flags/edge buckets exchanged over RCCL.
+
+Adds to the JSON line: "roofline" (dominant kernel = k_probe, HIP-event timed inside the library) and
+"cpu_baseline" (the reference itself, oracle/_ref, on a bounded sample of the same workload, rank 0, N=1 only).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+SLOT_ALG = 16                  # algorithmic index slot = 8-B key + 8-B payload
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def algorithmic_bytes(n_unique, n_ov, n_edges, L, k):
+    """A_total = N(2B + 4S + W S + 16) + N_ov B + 16 N_e; the probe kernel's share is
+    N(B + W S + 16) + N_ov B (read the read once, one slot per window, one neighbour per overlap, two ext records)."""
+    B = (L + 3) // 4
+    h = min(k, 64)
+    W = L - h + 1
+    total = n_unique * (2 * B + 4 * SLOT_ALG + W * SLOT_ALG + 16) + n_ov * B + 16 * n_edges
+    probe = n_unique * (B + W * SLOT_ALG + 16) + n_ov * B
+    return total, probe
+
+
+def cpu_baseline(args, s2, fx):
+    """Time the REFERENCE (oracle/_ref/libsage2ref_driver.so: the reference's own classes, built from
+    /root/reference by oracle/Makefile) on a bounded sample of the same workload, and diff its P.graph3
+    against ours on that sample.  Falls back to the CPU restatement (kind "port") when _ref is absent."""
+    n = args.cpu_sample_reads
+    cov = args.reads * args.read_len / args.genome
+    pd = dict(seed=args.seed + 1000, genome_len=int(n * args.read_len / cov), n_reads=n, read_len=args.read_len)
+    p = fx.synth_params(pd)
+    cores = os.cpu_count() or 1
+    threads = min(cores, args.cpu_threads) if args.cpu_threads else cores
+    sample = f"{n} x {args.read_len} bp reads, k={args.k}, {pd['genome_len']} bp genome, seed {pd['seed']} (same coverage as the GPU workload)"
+    tmp = tempfile.mkdtemp(prefix="sage2bench_")
+    out = None
+    try:
+        # our result on the sample: N_ov and the file to diff against
+        ctx = s2.Context(args.k, device=0)
+        g = s2.synth_genome(p)
+        ctx.reads_add_synth(p, g)
+        ctx.reads_organize()
+        ctx.run_steps23()
+        nov = ctx.overlap_stats().verified_overlaps
+        ours = os.path.join(tmp, "ours.graph3")
+        ctx.graph_save(ours)
+        ctx.close()
+        drv = os.path.join(ROOT, "oracle", "_ref", "libsage2ref_driver.so")
+        if os.path.exists(drv) and not args.cpu_port:
+            fa = os.path.join(tmp, "sample.fa")
+            s2.synth_write_fasta(p, fa)
+            L = C.CDLL(drv)
+            t = (C.c_double * 6)()
+            c = (C.c_ulonglong * 3)()
+            pref = os.path.join(tmp, "ref")
+            rc = L.sage2ref_run_steps123(fa.encode(), args.k, threads, pref.encode(), t, c)
+            assert rc == 0
+            T = t[2] + t[3] + t[4] + t[5]
+            same = open(pref + ".graph3", "rb").read() == open(ours, "rb").read()
+            out = dict(value=nov / T, unit="overlaps/s", cores=threads, kind="reference", sample=sample,
+                       seconds=dict(index=t[2], initial=t[3], reduce=t[4], sort_convert=t[5]),
+                       graph3_identical_to_gpu=bool(same))
+        else:
+            import oracle_lib as ol
+            bases, off = s2.synth_reads_ascii(p, g)
+            o = ol.Oracle(args.k, threads)
+            o.add_reads_ascii(bases, off)
+            o.organize()
+            o.run_all()
+            T = sum(o.time(i) for i in range(4))
+            gp = os.path.join(tmp, "port.graph3")
+            o.write_graph3(gp)
+            same = open(gp, "rb").read() == open(ours, "rb").read()
+            out = dict(value=o.counter("n_ov") / T, unit="overlaps/s", cores=threads, kind="port", sample=sample,
+                       seconds=dict(index=o.time(0), initial=o.time(1), reduce=o.time(2), sort_convert=o.time(3)),
+                       graph3_identical_to_gpu=bool(same))
+            o.close()
+    finally:
+        import shutil
+        shutil.rmtree(tmp, ignore_errors=True)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=10_000_000)      # BASELINE.json configs[1]
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--k", type=int, default=40)
+    ap.add_argument("--genome", type=int, default=30_000_000)
+    ap.add_argument("--seed", type=int, default=2)
+    ap.add_argument("--err-ppm", type=int, default=0)
+    ap.add_argument("--cpu-sample-reads", type=int, default=400_000)
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--cpu-port", action="store_true", help="time the CPU restatement instead of oracle/_ref")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import fixtures as fx
+    import sage2_amd as s2
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert torch.cuda.is_available(), "bench.py needs a GPU: the hot path has no CPU fallback"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    pd = dict(seed=args.seed, genome_len=args.genome, n_reads=args.reads, read_len=args.read_len, err_ppm=args.err_ppm)
+    p = fx.synth_params(pd)
+    t0 = time.time()
+    ctx = s2.Context(args.k, device=local, rank=rank, world=world)
+    if rank == 0:
+        g = s2.synth_genome(p)
+        ctx.reads_add_synth(p, g)
+        ctx.reads_organize()
+        st = ctx.reads_stats()
+        log(f"[bench] rank 0: {st.good_reads} good reads -> {st.unique_reads} unique, organised in {time.time() - t0:.1f} s")
+    if world > 1:
+        # rank 0 organised the reads; everybody else imports the HBM image (broadcast over RCCL)
+        meta = torch.zeros(6, dtype=torch.int64, device=dev)
+        if rank == 0:
+            meta = torch.tensor([st.unique_reads, st.words_per_read, st.max_read_length, st.good_reads, st.total_bp, 0], dtype=torch.int64, device=dev)
+        dist.broadcast(meta, 0)
+        n_u, wpr, mlen, good, bp, _ = meta.cpu().tolist()
+        if rank == 0:
+            words, freq = ctx.reads_export_words()
+            tw = torch.from_numpy(words.view(np.int64)).to(dev)
+        else:
+            tw = torch.empty((n_u + 1) * wpr, dtype=torch.int64, device=dev)
+        dist.broadcast(tw, 0)
+        if rank != 0:
+            ctx.reads_import_words(tw.cpu().numpy().view(np.uint64), n_u, wpr, mlen, np.ones(n_u + 1, dtype=np.uint16), good, bp)
+        del tw
+    st = ctx.reads_stats()
+
+    def step():
+        if world > 1:
+            from sage2_amd.dist import run_steps23_sharded
+            run_steps23_sharded(ctx, dev)
+        else:
+            ctx.run_steps23()
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    probe_ms0 = ctx.timings().probe_kernel_ms
+    launches0 = ctx.timings().probe_kernel_launches
+    t1 = time.perf_counter()
+    phase = dict(index_ms=0.0, probe_ms=0.0, reciprocal_ms=0.0, reduce_ms=0.0, convert_ms=0.0)
+    pk_ms, pk_n = 0.0, 0
+    for _ in range(args.steps):
+        step()
+        tm = ctx.timings()
+        for kph in phase:
+            phase[kph] += getattr(tm, kph)
+        pk_ms += tm.probe_kernel_ms
+        pk_n += tm.probe_kernel_launches
+    fence()
+    elapsed = time.perf_counter() - t1
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ost = ctx.overlap_stats()
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = ost.verified_overlaps / (elapsed / args.steps)
+
+    if rank == 0:
+        a_total, a_probe = algorithmic_bytes(st.unique_reads, ost.verified_overlaps, ost.edges, args.read_len, args.k)
+        lo, hi = ctx.shard_range()
+        share = (hi - lo) / max(st.unique_reads, 1)                  # this rank's share of the probe work
+        kern_ms = pk_ms / max(pk_n, 1)
+        ach = a_probe * share / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+        traffic = None
+        tj = os.path.join(ROOT, "profiles", "probe_traffic.json")
+        if os.path.exists(tj):
+            try:
+                traffic = json.load(open(tj)).get(f"{args.reads}x{args.read_len}_k{args.k}")
+            except Exception:
+                traffic = None
+        res = {
+            "metric": "overlaps/sec + edge-set bit-identity vs OpenMP ref, 150 bp reads k=40",
+            "value": value, "unit": "overlaps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "u64", "data": "synthetic",
+            "config": {"workload": f"{args.reads} x {args.read_len} bp synthetic paired-end reads, k={args.k}, {args.genome} bp uniform random genome, "
+                                   f"seed {args.seed}, err {args.err_ppm} ppm (BASELINE.json configs[1])",
+                       "unique_reads": st.unique_reads, "verified_overlaps": ost.verified_overlaps, "edges": ost.edges,
+                       "unresolved_reads": ost.left_to_explore, "partition": f"read-id range x{world}" if world > 1 else "single GPU",
+                       "timed_region": "index build + initial pass + reduce + sort/convert; reads resident in HBM"},
+            "phases_ms": {kph: v / args.steps for kph, v in phase.items()},
+            "reads_per_s": st.unique_reads / (elapsed / args.steps),
+            "roofline": {"bound": "hbm", "kernel": "k_probe", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": a_probe * share,
+                         "whole_path_achieved": a_total / (elapsed / args.steps) / 1e9, "whole_path_frac": a_total / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            ctx.close()
+            res["cpu_baseline"] = cpu_baseline(args, s2, fx)
+            if res["cpu_baseline"]:
+                res["speedup_vs_cpu_baseline"] = value / res["cpu_baseline"]["value"]
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

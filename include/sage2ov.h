@@ -87,6 +87,11 @@ int sage2ov_reads_load(sage2ov_ctx* ctx, const char* path);   /* loadReadsFromFi
 /* graph3 header fields when reads came from P.reads (good_reads / average length are not in that file;
  * main.cpp:141-148 likewise takes them from the graph file) */
 int sage2ov_reads_set_totals(sage2ov_ctx* ctx, uint64_t good_reads, uint64_t total_bp);
+/* The organised read store in its HBM word layout ((N+1) x words_per_read u64): one rank
+ * organises, the others import the image (multi-GPU: every rank needs all reads). */
+int sage2ov_reads_export_words(const sage2ov_ctx* ctx, uint64_t* words, uint64_t cap_words, uint16_t* frequency);
+int sage2ov_reads_import_words(sage2ov_ctx* ctx, const uint64_t* words, uint64_t n_unique, uint32_t words_per_read,
+                               uint32_t max_read_length, const uint16_t* frequency, uint64_t good_reads, uint64_t total_bp);
 
 /* ---- STEP 2: HashTable (economyGraph/hashTable.h:20-43) ---- */
 typedef struct sage2ov_index_stats {
@@ -151,7 +156,18 @@ int sage2ov_shard_record_bytes(const sage2ov_ctx* ctx, uint64_t* bytes_per_read)
 int sage2ov_overlap_probe_shard(sage2ov_ctx* ctx);                                    /* kernel only, own range */
 int sage2ov_shard_export_records(sage2ov_ctx* ctx, void* dev_dst, uint64_t max_reads);/* own range -> device buffer */
 int sage2ov_shard_import_records(sage2ov_ctx* ctx, const void* dev_src, uint64_t first_id, uint64_t n_reads);
-int sage2ov_overlap_reciprocal(sage2ov_ctx* ctx);                                     /* after all records are imported */
+/* containment marks (economyGraph.cpp:735) land on reads of ANY rank: 2*(N+1) bytes (two bit planes) that the
+ * caller MAX-all-reduces (= bitwise OR) between export and import */
+int sage2ov_shard_flags_bytes(const sage2ov_ctx* ctx, uint64_t* bytes);
+int sage2ov_shard_export_flags(sage2ov_ctx* ctx, void* dev_dst);
+int sage2ov_shard_import_flags(sage2ov_ctx* ctx, const void* dev_src);
+/* reciprocal test for every read (cheap, replicated), edge buckets only for this rank's reads */
+int sage2ov_overlap_reciprocal(sage2ov_ctx* ctx);
+/* per-rank edge buckets (16-byte records {from,to,len,type}): all-gather counts, then the padded buckets,
+ * then hand every rank the concatenation */
+int sage2ov_shard_edges_count(const sage2ov_ctx* ctx, uint64_t* n);
+int sage2ov_shard_edges_export(sage2ov_ctx* ctx, void* dev_dst, uint64_t cap_edges);
+int sage2ov_shard_edges_set(sage2ov_ctx* ctx, const void* dev_src, uint64_t n_edges);
 
 /* ---- profiling hooks: HIP-event timings of the last run, milliseconds ---- */
 typedef struct sage2ov_timings {

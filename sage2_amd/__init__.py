@@ -157,6 +157,19 @@ class Context:
         self._chk(lib().sage2ov_reads_export(self._h, C.c_void_p(packed.ctypes.data), C.c_uint64(stride), C.c_void_p(length.ctypes.data), C.c_void_p(freq.ctypes.data)))
         return packed, length, freq
 
+    def reads_export_words(self):
+        s = self.reads_stats()
+        words = np.zeros((s.unique_reads + 1) * s.words_per_read, dtype=np.uint64)
+        freq = np.zeros(s.unique_reads + 1, dtype=np.uint16)
+        self._chk(lib().sage2ov_reads_export_words(self._h, C.c_void_p(words.ctypes.data), C.c_uint64(words.size), C.c_void_p(freq.ctypes.data)))
+        return words, freq
+
+    def reads_import_words(self, words, n_unique, words_per_read, max_read_length, freq, good_reads, total_bp):
+        words = np.ascontiguousarray(words, dtype=np.uint64)
+        freq = np.ascontiguousarray(freq, dtype=np.uint16)
+        self._chk(lib().sage2ov_reads_import_words(self._h, C.c_void_p(words.ctypes.data), C.c_uint64(n_unique), C.c_uint32(words_per_read),
+                                                   C.c_uint32(max_read_length), C.c_void_p(freq.ctypes.data), C.c_uint64(good_reads), C.c_uint64(total_bp)))
+
     def reads_save(self, path):
         self._chk(lib().sage2ov_reads_save(self._h, path.encode()))
 
@@ -246,3 +259,25 @@ class Context:
 
     def overlap_reciprocal(self):
         self._chk(lib().sage2ov_overlap_reciprocal(self._h))
+
+    def shard_flags_bytes(self):
+        b = C.c_uint64()
+        self._chk(lib().sage2ov_shard_flags_bytes(self._h, C.byref(b)))
+        return b.value
+
+    def shard_export_flags(self, dev_ptr):
+        self._chk(lib().sage2ov_shard_export_flags(self._h, C.c_void_p(dev_ptr)))
+
+    def shard_import_flags(self, dev_ptr):
+        self._chk(lib().sage2ov_shard_import_flags(self._h, C.c_void_p(dev_ptr)))
+
+    def shard_edges_count(self):
+        n = C.c_uint64()
+        self._chk(lib().sage2ov_shard_edges_count(self._h, C.byref(n)))
+        return n.value
+
+    def shard_edges_export(self, dev_ptr, cap):
+        self._chk(lib().sage2ov_shard_edges_export(self._h, C.c_void_p(dev_ptr), C.c_uint64(cap)))
+
+    def shard_edges_set(self, dev_ptr, n):
+        self._chk(lib().sage2ov_shard_edges_set(self._h, C.c_void_p(dev_ptr), C.c_uint64(n)))

@@ -527,9 +527,9 @@ __device__ __forceinline__ void emit_edge(EdgeCand* cand, u64 cap, u64* counters
     if (p < cap) cand[p] = e;
 }
 __global__ void k_recip_emit(u64 N, const u64* __restrict__ reads, int S, const u64* __restrict__ right, const u64* __restrict__ left,
-                             const uint8_t* __restrict__ status, EdgeCand* cand, u64 cap, u64* counters) {
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x + 1;
-    if (i > N || status[i] != 4) return;
+                             const uint8_t* __restrict__ status, EdgeCand* cand, u64 cap, u64* counters, u64 elo, u64 ehi) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x + elo;
+    if (i >= ehi || i > N || status[i] != 4) return;
     u64 l = left[i], r = right[i]; u64 lid = l & ID_MASK, rid = r & ID_MASK;
     if (!(lid < i && status[lid] == 4)) emit_edge(cand, cap, counters, reads, S, i, lid, (u32)(l >> 42), ((l >> 40) & 3) == 0 ? 0u : 1u);   // :462-467
     if (!(rid < i && status[rid] == 4)) emit_edge(cand, cap, counters, reads, S, i, rid, (u32)(r >> 42), ((r >> 40) & 3) == 0 ? 3u : 2u);   // :468-473
@@ -754,6 +754,38 @@ __global__ void k_unpack_records(u64 first, u64 n, const Record* in, u64* right,
     Record r = in[x]; u64 i = first + x; right[i] = r.right; left[i] = r.left; conn[i] = r.conn;
     (void)own; cflag[i] = r.cflag;
 }
+// containment flags travel as two byte planes (bit0 plane, bit1 plane) so that a MAX all-reduce is a bitwise OR
+__global__ void k_flags_export(u64 n, const u32* __restrict__ cflag, uint8_t* out) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; if (i >= n) return;
+    u32 f = cflag[i]; out[i] = f & 1u; out[n + i] = (f >> 1) & 1u;
+}
+__global__ void k_flags_import(u64 n, const uint8_t* __restrict__ in, u32* cflag) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; if (i >= n) return;
+    cflag[i] = (in[i] ? 1u : 0u) | (in[n + i] ? 2u : 0u);
+}
+int dev_export_flags(Device* d, void* dst, std::string& err) {
+    HIPCHK(hipSetDevice(d->ordinal));
+    hipLaunchKernelGGL(k_flags_export, dim3(grid_for(d->N + 1, 256)), dim3(256), 0, d->stream, (u64)(d->N + 1), d->cflag, (uint8_t*)dst);
+    HIPCHK(hipStreamSynchronize(d->stream)); return 0;
+}
+int dev_import_flags(Device* d, const void* src, std::string& err) {
+    HIPCHK(hipSetDevice(d->ordinal));
+    hipLaunchKernelGGL(k_flags_import, dim3(grid_for(d->N + 1, 256)), dim3(256), 0, d->stream, (u64)(d->N + 1), (const uint8_t*)src, d->cflag);
+    HIPCHK(hipStreamSynchronize(d->stream)); return 0;
+}
+uint64_t dev_cand_count(Device* d) { return d->n_cand; }
+int dev_export_cands(Device* d, void* dst, uint64_t cap, std::string& err) {
+    HIPCHK(hipSetDevice(d->ordinal));
+    if (d->n_cand > cap) { err = "candidate export buffer too small"; return SAGE2OV_ERR_ARG; }
+    if (d->n_cand) HIPCHK(hipMemcpyAsync(dst, d->cand, d->n_cand * sizeof(EdgeCand), hipMemcpyDeviceToDevice, d->stream));
+    HIPCHK(hipStreamSynchronize(d->stream)); return 0;
+}
+int dev_set_cands(Device* d, const void* src, uint64_t n, std::string& err) {      // replace the candidate list (device source)
+    HIPCHK(hipSetDevice(d->ordinal));
+    if (n > d->cand_cap) { hipFree(d->cand); d->cand = nullptr; d->cand_cap = n + 1024; HIPCHK(hipMalloc(&d->cand, d->cand_cap * sizeof(EdgeCand))); }
+    if (n) HIPCHK(hipMemcpyAsync(d->cand, src, n * sizeof(EdgeCand), hipMemcpyDeviceToDevice, d->stream));
+    HIPCHK(hipStreamSynchronize(d->stream)); d->n_cand = n; return 0;
+}
 int dev_export_records(Device* d, void* dst, uint64_t lo, uint64_t hi, std::string& err) {
     HIPCHK(hipSetDevice(d->ordinal));
     if (hi > lo) hipLaunchKernelGGL(k_pack_records, dim3(grid_for(hi - lo, 256)), dim3(256), 0, d->stream, (u64)lo, (u64)hi, d->right, d->left, d->conn, d->cflag, (Record*)dst);
@@ -767,14 +799,15 @@ int dev_import_records(Device* d, const void* src, uint64_t first, uint64_t n, s
     return 0;
 }
 
-int dev_reciprocal(Device* d, uint64_t* n_ov, uint64_t* contained, uint64_t* contained_size, std::string& err) {
+int dev_reciprocal(Device* d, uint64_t emit_lo, uint64_t emit_hi, uint64_t* n_ov, uint64_t* contained, uint64_t* contained_size, std::string& err) {
     HIPCHK(hipSetDevice(d->ordinal));
     const u64 N = d->N;
     HIPCHK(hipEventRecord(d->ev[0], d->stream));
     HIPCHK(hipMemsetAsync(d->d_counters, 0, 8 * sizeof(u64), d->stream));
     HIPCHK(hipMemsetAsync(d->status, 0, N + 1, d->stream));
     hipLaunchKernelGGL(k_recip_cond, dim3(grid_for(N, 256)), dim3(256), 0, d->stream, N, d->right, d->left, d->conn, d->cflag, d->status, d->d_counters);
-    hipLaunchKernelGGL(k_recip_emit, dim3(grid_for(N, 256)), dim3(256), 0, d->stream, N, d->reads, d->S, d->right, d->left, d->status, d->cand, d->cand_cap, d->d_counters);
+    if (emit_hi > emit_lo)
+        hipLaunchKernelGGL(k_recip_emit, dim3(grid_for(emit_hi - emit_lo, 256)), dim3(256), 0, d->stream, N, d->reads, d->S, d->right, d->left, d->status, d->cand, d->cand_cap, d->d_counters, (u64)emit_lo, (u64)emit_hi);
     u64 c[8];
     HIPCHK(hipMemcpyAsync(c, d->d_counters, sizeof c, hipMemcpyDeviceToHost, d->stream));
     HIPCHK(hipEventRecord(d->ev[1], d->stream));

@@ -417,6 +417,25 @@ int sage2ov_reads_load(sage2ov_ctx* c, const char* path) {                      
     c->organized = false;
     return upload(c);
 }
+// word-layout image of the organised reads (what lives in HBM): lets one rank organise and the others import
+int sage2ov_reads_export_words(const sage2ov_ctx* c, uint64_t* words, uint64_t cap_words, uint16_t* frequency) {
+    if (!c || !c->organized || !words) return SAGE2OV_ERR_ARG;
+    if (cap_words < c->words.size()) return SAGE2OV_ERR_ARG;
+    memcpy(words, c->words.data(), c->words.size() * sizeof(uint64_t));
+    if (frequency) memcpy(frequency, c->freq.data(), (c->N + 1) * sizeof(uint16_t));
+    return SAGE2OV_OK;
+}
+int sage2ov_reads_import_words(sage2ov_ctx* c, const uint64_t* words, uint64_t n_unique, uint32_t words_per_read, uint32_t max_read_length,
+                               const uint16_t* frequency, uint64_t good_reads, uint64_t total_bp) {
+    if (!c || !words) return SAGE2OV_ERR_ARG;
+    if (words_per_read != 4 && words_per_read != 8 && words_per_read != 16) return c->fail(SAGE2OV_ERR_ARG, "words_per_read must be 4, 8 or 16");
+    c->N = n_unique; c->S = (int)words_per_read; c->maxL = (int)max_read_length;
+    c->words.assign(words, words + (n_unique + 1) * words_per_read);
+    c->len.assign(n_unique + 1, 0); c->freq.assign(n_unique + 1, 0);
+    for (uint64_t i = 1; i <= n_unique; i++) { c->len[i] = (uint16_t)(c->words[i * c->S + c->S - 1] & 0xFFFF); c->freq[i] = frequency ? frequency[i] : 1; }
+    c->goodReads = good_reads; c->totalBP = total_bp; c->totalReads = good_reads; c->organized = false;
+    return upload(c);
+}
 int sage2ov_reads_set_totals(sage2ov_ctx* c, uint64_t good, uint64_t bp) { if (!c) return SAGE2OV_ERR_ARG; c->goodReads = good; c->totalBP = bp; return SAGE2OV_OK; }
 
 // ------------------------------------------------------------------------------------------ step 2
@@ -463,11 +482,18 @@ int sage2ov_shard_import_records(sage2ov_ctx* c, const void* src, uint64_t first
 }
 int sage2ov_overlap_reciprocal(sage2ov_ctx* c) {
     if (!c) return SAGE2OV_ERR_ARG; if (!c->probed) return c->fail(SAGE2OV_ERR_ARG, "probe first");
-    uint64_t nov, cont, csize; int rc = dev_reciprocal(c->dev, &nov, &cont, &csize, c->err); if (rc) return rc;
+    uint64_t lo, hi; sage2ov_shard_range(c, &lo, &hi);
+    uint64_t nov, cont, csize; int rc = dev_reciprocal(c->dev, lo, hi, &nov, &cont, &csize, c->err); if (rc) return rc;
     c->ostats = sage2ov_overlap_stats{}; c->ostats.verified_overlaps = nov; c->ostats.contained_extension = cont; c->ostats.contained_size = csize;
     c->ostats.left_to_explore = c->N - cont - csize;
     c->reciprocalDone = true; c->reduced = c->converted = false; return SAGE2OV_OK;
 }
+int sage2ov_shard_flags_bytes(const sage2ov_ctx* c, uint64_t* b) { if (!c || !b) return SAGE2OV_ERR_ARG; *b = 2 * (c->N + 1); return SAGE2OV_OK; }
+int sage2ov_shard_export_flags(sage2ov_ctx* c, void* dst) { if (!c || !dst) return SAGE2OV_ERR_ARG; if (!c->probed) return c->fail(SAGE2OV_ERR_ARG, "probe first"); return dev_export_flags(c->dev, dst, c->err); }
+int sage2ov_shard_import_flags(sage2ov_ctx* c, const void* src) { if (!c || !src) return SAGE2OV_ERR_ARG; if (!c->probed) return c->fail(SAGE2OV_ERR_ARG, "probe first"); return dev_import_flags(c->dev, src, c->err); }
+int sage2ov_shard_edges_count(const sage2ov_ctx* c, uint64_t* n) { if (!c || !n || !c->reciprocalDone) return SAGE2OV_ERR_ARG; *n = dev_cand_count(c->dev); return SAGE2OV_OK; }
+int sage2ov_shard_edges_export(sage2ov_ctx* c, void* dst, uint64_t cap) { if (!c || !dst) return SAGE2OV_ERR_ARG; if (!c->reciprocalDone) return c->fail(SAGE2OV_ERR_ARG, "reciprocal pass first"); return dev_export_cands(c->dev, dst, cap, c->err); }
+int sage2ov_shard_edges_set(sage2ov_ctx* c, const void* src, uint64_t n) { if (!c || (!src && n)) return SAGE2OV_ERR_ARG; if (!c->reciprocalDone) return c->fail(SAGE2OV_ERR_ARG, "reciprocal pass first"); return dev_set_cands(c->dev, src, n, c->err); }
 int sage2ov_overlap_initial(sage2ov_ctx* c) {
     if (!c) return SAGE2OV_ERR_ARG;
     if (c->cfg.world > 1) return c->fail(SAGE2OV_ERR_ARG, "multi-GPU contexts use probe_shard / export / import / reciprocal");

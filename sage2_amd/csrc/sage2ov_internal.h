@@ -48,7 +48,13 @@ int dev_probe(Device* d, uint64_t lo, uint64_t hi, std::string& err);
 int dev_export_records(Device* d, void* dev_dst, uint64_t lo, uint64_t hi, std::string& err);
 int dev_import_records(Device* d, const void* dev_src, uint64_t first, uint64_t n, std::string& err);
 // reciprocal pass (economyGraph.cpp:455-480) over all reads -> status[], edge candidates on device
-int dev_reciprocal(Device* d, uint64_t* n_ov, uint64_t* contained, uint64_t* contained_size, std::string& err);
+// cond() for every read; edge candidates are emitted only for reads in [emit_lo, emit_hi)
+int dev_reciprocal(Device* d, uint64_t emit_lo, uint64_t emit_hi, uint64_t* n_ov, uint64_t* contained, uint64_t* contained_size, std::string& err);
+int dev_export_flags(Device* d, void* dev_dst, std::string& err);      // 2*(N+1) bytes
+int dev_import_flags(Device* d, const void* dev_src, std::string& err);
+uint64_t dev_cand_count(Device* d);
+int dev_export_cands(Device* d, void* dev_dst, uint64_t cap, std::string& err);   // 16 bytes per candidate
+int dev_set_cands(Device* d, const void* dev_src, uint64_t n, std::string& err);
 int dev_download_initial(Device* d, uint64_t* right, uint64_t* left, uint8_t* status, uint32_t* conn, std::string& err);
 // directional hit lists of status-0 reads (economyGraph.cpp:591-633), sorted by (from, seq)
 int dev_unresolved_hits(Device* d, std::vector<Hit>& hits, uint64_t* n_unresolved, std::string& err);

@@ -1,0 +1,100 @@
+"""Multi-GPU orchestration of steps 2-3: one process per GPU, torch.distributed (backend "nccl" = RCCL over
+xGMI on the GPU box, "gloo" in CPU tests).  The read set and the index are replicated; read ids are
+range-partitioned for the probe/verify kernel.  Exchange steps -- all bulk, one-shot:
+
+  1. all-gather of the fixed-size per-read records (right ext, left ext, connections, flags: 24 B/read):
+     the reciprocal test reads the NEIGHBOUR's record (economyGraph.cpp:460);
+  2. MAX all-reduce (= OR) of the two containment bit planes: a containment mark (economyGraph.cpp:735)
+     lands on a read of any rank;
+  3. all-gather of the variable-size per-rank edge buckets (counts first, then max-padded buffers).
+
+The tensor plumbing below is backend-agnostic (it is what the gloo tests exercise); `run_steps23_sharded`
+binds it to a sage2_amd.Context.
+"""
+import torch
+import torch.distributed as dist
+
+RECORD_BYTES = 24
+EDGE_BYTES = 16
+
+
+def _sync(t: torch.Tensor):
+    """collectives run on torch's stream, the library on its own: fence before handing buffers over"""
+    if t.is_cuda:
+        torch.cuda.current_stream(t.device).synchronize()
+
+
+def shard_range(n_unique, rank, world):
+    """ids [lo, hi) of rank `rank`; identical to sage2ov_shard_range."""
+    return 1 + (n_unique * rank) // world, 1 + (n_unique * (rank + 1)) // world
+
+
+def max_shard(n_unique, world):
+    return max(shard_range(n_unique, r, world)[1] - shard_range(n_unique, r, world)[0] for r in range(world))
+
+
+def allgather_records(send: torch.Tensor, n_unique: int, group=None):
+    """send: uint8 [max_shard*24] holding this rank's records (padded).  Returns a list of (first_id, n, tensor)."""
+    world = dist.get_world_size(group)
+    recv = torch.empty(world * send.numel(), dtype=torch.uint8, device=send.device)
+    dist.all_gather_into_tensor(recv, send, group=group)
+    _sync(recv)
+    out = []
+    for r in range(world):
+        lo, hi = shard_range(n_unique, r, world)
+        out.append((lo, hi - lo, recv[r * send.numel(): r * send.numel() + (hi - lo) * RECORD_BYTES]))
+    return out
+
+
+def allreduce_flags(planes: torch.Tensor, group=None):
+    dist.all_reduce(planes, op=dist.ReduceOp.MAX, group=group)
+    _sync(planes)
+    return planes
+
+
+def allgather_edge_buckets(bucket: torch.Tensor, n_edges: int, group=None):
+    """bucket: uint8 tensor with this rank's n_edges*16 bytes (may be longer).  Returns the concatenation of
+    all ranks' buckets in rank order and the total edge count."""
+    world = dist.get_world_size(group)
+    cnt = torch.tensor([n_edges], dtype=torch.int64, device=bucket.device)
+    cnts = torch.empty(world, dtype=torch.int64, device=bucket.device)
+    dist.all_gather_into_tensor(cnts, cnt, group=group)
+    cnts = cnts.cpu().tolist()
+    pad = max(max(cnts), 1) * EDGE_BYTES
+    send = torch.zeros(pad, dtype=torch.uint8, device=bucket.device)
+    send[: n_edges * EDGE_BYTES] = bucket[: n_edges * EDGE_BYTES]
+    recv = torch.empty(world * pad, dtype=torch.uint8, device=bucket.device)
+    dist.all_gather_into_tensor(recv, send, group=group)
+    _sync(recv)
+    parts = [recv[r * pad: r * pad + cnts[r] * EDGE_BYTES] for r in range(world)]
+    return torch.cat(parts) if parts else recv[:0], sum(cnts)
+
+
+def run_steps23_sharded(ctx, device, group=None):
+    """The timed region (index build + initial + reduce + convert) on `world` GPUs.  Every rank ends up with the
+    complete canonical edge list."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    n = ctx.reads_stats().unique_reads
+    ctx.index_build()
+    ctx.overlap_probe_shard()
+    ms = max_shard(n, world)
+    send = torch.zeros(ms * RECORD_BYTES, dtype=torch.uint8, device=device)
+    ctx.shard_export_records(send.data_ptr(), ms)
+    for first, cnt, t in allgather_records(send, n, group):
+        if cnt:
+            t = t.contiguous()
+            ctx.shard_import_records(t.data_ptr(), first, cnt)
+    planes = torch.zeros(ctx.shard_flags_bytes(), dtype=torch.uint8, device=device)
+    ctx.shard_export_flags(planes.data_ptr())
+    allreduce_flags(planes, group)
+    ctx.shard_import_flags(planes.data_ptr())
+    ctx.overlap_reciprocal()
+    ne = ctx.shard_edges_count()
+    bucket = torch.zeros(max(ne, 1) * EDGE_BYTES, dtype=torch.uint8, device=device)
+    ctx.shard_edges_export(bucket.data_ptr(), max(ne, 1))
+    allb, total = allgather_edge_buckets(bucket, ne, group)
+    allb = allb.contiguous()
+    _sync(allb)
+    ctx.shard_edges_set(allb.data_ptr() if total else 0, total)
+    ctx.overlap_reduce()
+    ctx.overlap_convert()
