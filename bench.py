@@ -180,8 +180,6 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    probe_ms0 = ctx.timings().probe_kernel_ms
-    launches0 = ctx.timings().probe_kernel_launches
     t1 = time.perf_counter()
     phase = dict(index_ms=0.0, probe_ms=0.0, reciprocal_ms=0.0, reduce_ms=0.0, convert_ms=0.0)
     pk_ms, pk_n = 0.0, 0

@@ -144,6 +144,14 @@ int sage2ov_edges_count(const sage2ov_ctx* ctx, uint64_t* n);
 int sage2ov_edges_export(sage2ov_ctx* ctx, sage2ov_edge* out, uint64_t cap);
 int sage2ov_graph_save(sage2ov_ctx* ctx, const char* path);     /* saveOverlapGraphInFile (overlapGraph.cpp:338) -> P.graph3 */
 
+/* diagnostic: table census {occupied, inline, claimed-but-unfilled, zero-tag, entries in short CSR buckets} */
+int sage2ov_debug_table(sage2ov_ctx* ctx, uint64_t* out5);
+/* diagnostic: the four index keys (hashTable.cpp:96-104) of every read as the device computes them: 8N u64 (hi,lo per entry) */
+int sage2ov_debug_keys(sage2ov_ctx* ctx, uint64_t* out);
+/* diagnostic: the directional hit list (economyGraph.cpp:591-633: to, edge type, length) of EVERY read, rows of
+ * 5 x u32 {from, to, type, length, sequence-number}, sorted by (from, sequence).  out may be NULL to size. */
+int sage2ov_debug_all_hits(sage2ov_ctx* ctx, uint32_t* out, uint64_t cap_rows, uint64_t* n_rows);
+
 /* whole timed region of SURVEY 8(d): index build + initial + reduce + convert, reads already in HBM */
 int sage2ov_run_steps23(sage2ov_ctx* ctx);
 
@@ -176,6 +184,7 @@ typedef struct sage2ov_timings {
     uint64_t probe_kernel_launches;
 } sage2ov_timings;
 int sage2ov_timings_get(const sage2ov_ctx* ctx, sage2ov_timings* out);
+int sage2ov_timings_reset(sage2ov_ctx* ctx);
 void* sage2ov_stream(sage2ov_ctx* ctx);   /* hipStream_t the context launches on */
 
 /* ---- deterministic synthetic reads (repo-owned, not part of the reference) ---- */

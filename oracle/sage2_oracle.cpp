@@ -504,13 +504,14 @@ void orc_run_all(void* p) { auto* o = (Oracle*)p; o->build_index(); o->initial_p
 int orc_write_reads(void* p, const char* path) { return ((Oracle*)p)->write_reads(path); }
 int orc_write_graph3(void* p, const char* path) { return ((Oracle*)p)->write_graph3(path); }
 // counters: 0 N, 1 numberOfReads, 2 totalReads, 3 totalBP, 4 avgLen, 5 nOv, 6 contained, 7 containedSize,
-// 8 edgesInserted, 9 transRemoved, 10 nEdgesOut, 11 nLongBuckets, 12 M, 13 stride, 14 h
+// 8 edgesInserted, 9 transRemoved, 10 nEdgesOut, 11 nLongBuckets, 12 M, 13 stride, 14 h, 15 distinct keys
 uint64_t orc_counter(void* p, int which) {
     auto* o = (Oracle*)p;
     switch (which) { case 0: return o->N; case 1: return o->numberOfReads; case 2: return o->totalReads; case 3: return o->totalBP;
         case 4: return o->avg_len(); case 5: return o->nOv; case 6: return o->contained; case 7: return o->containedSize;
         case 8: return o->edgesInserted; case 9: return o->transRemoved; case 10: return o->out.size(); case 11: return o->nLong;
-        case 12: return o->M; case 13: return (uint64_t)o->stride; case 14: return (uint64_t)o->h; }
+        case 12: return o->M; case 13: return (uint64_t)o->stride; case 14: return (uint64_t)o->h;
+        case 15: { uint64_t n = 0; for (auto hd : o->slotHead) n += hd >= 0; return n; } }
     return 0;
 }
 double orc_time(void* p, int which) { auto* o = (Oracle*)p; double t[4] = {o->tIndex, o->tInitial, o->tReduce, o->tConvert}; return which >= 0 && which < 4 ? t[which] : 0; }
@@ -537,6 +538,25 @@ void orc_export_edges(void* p, uint64_t* e) {
 int orc_lookup(void* p, uint64_t v0, uint64_t v1, uint64_t* entries, int cap) {
     auto* o = (Oracle*)p; uint64_t miss = 0; int64_t s = o->search(Key{v0, v1}, miss); if (s < 0) return 0;
     int n = 0; for (int64_t e = o->slotHead[s]; e >= 0; e = o->entNext[e]) { if (n < cap) entries[n] = o->entVal[e]; n++; }
+    return n;
+}
+// diagnostic: hits of read r1 with the semantics of economyGraph.cpp:591-633 ignoring the explored filter;
+// rows {to, type, len}; returns the count
+int orc_debug_hits(void* p, uint64_t r1, int64_t* out, int cap) {
+    auto* o = (Oracle*)p; int n = 0; bool dummy; uint64_t miss = 0;
+    const int L1 = o->len[r1], h = o->h, k = o->k;
+    for (int j = 0; j <= L1 - h; j++) {
+        int64_t idx = o->search(get128(o->F(r1), j, h), miss); if (idx < 0) continue;
+        for (int64_t e = o->slotHead[idx]; e >= 0; e = o->entNext[e]) {
+            uint64_t r2 = o->entVal[e] >> 2; int type = o->entVal[e] & 3; const int L2 = o->len[r2]; int ovl = 0, t = -1;
+            if (r2 == r1) continue;
+            if (type == 0 && j <= L1 - k && o->compare_ext(o->F(r1), o->F(r2), j, L1, L2, true, &dummy)) { ovl = L2 - (L1 - j); t = 3; }
+            else if (type == 1 && j >= k - h && o->compare_ext(o->R(r1), o->R(r2), L1 - j - h, L1, L2, true, &dummy)) { ovl = L2 - j - h; t = 0; }
+            else if (type == 2 && j <= L1 - k && o->compare_ext(o->F(r1), o->R(r2), j, L1, L2, true, &dummy)) { ovl = L2 - (L1 - j); t = 2; }
+            else if (type == 3 && j >= k - h && o->compare_ext(o->R(r1), o->F(r2), L1 - j - h, L1, L2, true, &dummy)) { ovl = L2 - j - h; t = 1; }
+            if (t >= 0) { if (n < cap) { out[3 * n] = (int64_t)r2; out[3 * n + 1] = t; out[3 * n + 2] = ovl; } n++; }
+        }
+    }
     return n;
 }
 // bit-utility known-answer hooks

@@ -239,6 +239,16 @@ class Context:
         self._chk(lib().sage2ov_timings_get(self._h, C.byref(t)))
         return t
 
+    def debug_all_hits(self):
+        n = C.c_uint64()
+        self._chk(lib().sage2ov_debug_all_hits(self._h, None, C.c_uint64(0), C.byref(n)))
+        out = np.zeros((n.value, 5), dtype=np.uint32)
+        self._chk(lib().sage2ov_debug_all_hits(self._h, C.c_void_p(out.ctypes.data), C.c_uint64(n.value), C.byref(n)))
+        return out
+
+    def timings_reset(self):
+        self._chk(lib().sage2ov_timings_reset(self._h))
+
     def stream(self):
         return lib().sage2ov_stream(self._h)
 

@@ -7,6 +7,8 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
+#include <vector>
 #include "sage2ov.h"
 #include "sage2ov_internal.h"
 
@@ -44,6 +46,7 @@ struct Device {
     // final edges (device resident)
     FinalEdge* final_edges = nullptr; u64 n_final = 0;
     DevTimings tm;
+    std::vector<u32> dbg_where; std::vector<u64> dbg_keys;
 };
 
 // =============================================================================================
@@ -57,12 +60,14 @@ __device__ __forceinline__ u64 mask_top(int nb) {   // top 2*nb bits set, nb in 
     return nb >= 32 ? ~0ull : (nb <= 0 ? 0ull : (~0ull << (64 - 2 * nb)));
 }
 // 64 bits of a big-endian bit string starting at bit `bitpos`; words beyond `nw` read as 0
+// (branch free: both words are always loaded, the second from a clamped index)
 __device__ __forceinline__ u64 bits64(const u64* w, int nw, int bitpos) {
-    int q = bitpos >> 6, r = bitpos & 63;
-    u64 a = w[q];
-    if (r == 0) return a;
-    u64 b = (q + 1 < nw) ? w[q + 1] : 0ull;
-    return (a << r) | (b >> (64 - r));
+    const int q = bitpos >> 6, r = bitpos & 63;
+    const int q1 = (q + 1 < nw) ? q + 1 : q;
+    const u64 a = w[q];
+    u64 b = w[q1];
+    b = (q + 1 < nw) ? b : 0ull;
+    return (a << r) | ((b >> 1) >> (63 - r));
 }
 // h-base key starting at base j, right aligned in (hi,lo): the integer (v0<<64|v1) of utils.cpp:171-187
 __device__ __forceinline__ void key_at(const u64* w, int nw, int j, int h, u64& hi, u64& lo) {
@@ -129,12 +134,30 @@ __device__ __forceinline__ void entry_key(const u64* __restrict__ reads, int S, 
     if (t >= 2) rc_key(phi, plo, h, hi, lo); else { hi = phi; lo = plo; }   // hashTable.cpp:96-104
 }
 
-__global__ void k_index_count(const u64* __restrict__ reads, u64 N, int S, int h, u64 seed, u64* slots, u64 T, u32* cnt, u32* where) {
+__global__ void k_zero64(u64* p, u64 n) { u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; const u64 st = (u64)gridDim.x * blockDim.x; for (; i < n; i += st) p[i] = 0; }
+template <int VARIANT>
+__global__ void k_index_count_v(const u64* __restrict__ reads, u64 N, int S, int h, u64 seed, u64* slots, u64 T, u32* cnt, u32* where) {
     u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     const u64 stride = (u64)gridDim.x * blockDim.x;
     for (; e < 4 * N; e += stride) {
         u64 hi, lo; entry_key(reads, S, h, (e >> 2) + 1, (int)(e & 3), hi, lo);
         u64 hv = hash_key(hi, lo, seed); const u64 tag = tag_of(hv); u64 idx = home_of(hv, T);
+        for (;;) {
+            u64 old = atomicCAS((u64*)&slots[idx], 0ull, tag << SLOT_TAG_SHIFT);      // always go through the atomic
+            if (old == 0 || (old >> SLOT_TAG_SHIFT) == tag) break;
+            if (++idx == T) idx = 0;
+        }
+        atomicAdd(&cnt[idx], 1u);
+        where[e] = (u32)idx;
+    }
+}
+__global__ void k_index_count(const u64* __restrict__ reads, u64 N, int S, int h, u64 seed, u64* slots, u64 T, u32* cnt, u32* where, u64* dbg) {
+    u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (; e < 4 * N; e += stride) {
+        u64 hi, lo; entry_key(reads, S, h, (e >> 2) + 1, (int)(e & 3), hi, lo);
+        u64 hv = hash_key(hi, lo, seed); const u64 tag = tag_of(hv); u64 idx = home_of(hv, T);
+        if (dbg) { dbg[4 * e] = hi; dbg[4 * e + 1] = lo; dbg[4 * e + 2] = hv; dbg[4 * e + 3] = idx; }
         for (;;) {
             u64 s = __hip_atomic_load(&slots[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (s == 0) {
@@ -146,6 +169,22 @@ __global__ void k_index_count(const u64* __restrict__ reads, u64 N, int S, int h
         atomicAdd(&cnt[idx], 1u);
         where[e] = (u32)idx;
     }
+}
+__global__ void k_debug_table(const u64* __restrict__ slots, u64 T, u64* out) {
+    u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x; if (idx >= T) return;
+    u64 s = slots[idx]; if (s == 0) return;
+    u32 c7 = (u32)(s >> SLOT_CNT_SHIFT) & 127u;
+    atomicAdd(&out[0], 1ull);
+    if (c7 == 1) atomicAdd(&out[1], 1ull);
+    if (c7 == 0) atomicAdd(&out[2], 1ull);                 // claimed, never filled
+    if ((s >> SLOT_TAG_SHIFT) == 0) atomicAdd(&out[3], 1ull);
+    if (c7 >= 2 && c7 < 127) atomicAdd(&out[4], (u64)c7);
+}
+__global__ void k_debug_keys(const u64* __restrict__ reads, u64 N, int S, int h, u64* out) {
+    u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= 4 * N) return;
+    u64 hi, lo; entry_key(reads, S, h, (e >> 2) + 1, (int)(e & 3), hi, lo);
+    out[2 * e] = hi; out[2 * e + 1] = lo;
 }
 // counters: [0] csr total, [1] occupied slots, [2] number of big buckets, [3] impurity flag, [4] pure long buckets
 __global__ void k_index_alloc(u64* slots, u64 T, const u32* __restrict__ cnt, u64* counters, u64* big, u32 big_cap) {
@@ -274,10 +313,9 @@ struct WaveLds {
 
 template <int S>
 __device__ __forceinline__ u64 ybits(const u64 (*y)[64], u32 lane, int bitpos) {
-    int q = bitpos >> 6, r = bitpos & 63;
-    u64 a = y[q][lane];
-    if (r == 0) return a;
-    return (a << r) | (y[q + 1][lane] >> (64 - r));
+    const int q = bitpos >> 6, r = bitpos & 63;
+    const u64 a = y[q][lane], b = y[q + 1][lane];          // row S is a zero pad
+    return (a << r) | ((b >> 1) >> (63 - r));
 }
 // n bases of X from xa equal n bases of candidate (lane column of y) from ya
 template <int S>
@@ -659,11 +697,20 @@ int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t
     HIPCHK(hipEventRecord(d->ev[0], d->stream));
     *rebuilds = 0;
     for (int attempt = 0;; attempt++) {
+        if (getenv("SAGE2OV_DBG_ZERO_KERNEL")) {
+            hipLaunchKernelGGL(k_zero64, dim3(2048), dim3(256), 0, d->stream, d->slots, (u64)d->T);
+            hipLaunchKernelGGL(k_zero64, dim3(2048), dim3(256), 0, d->stream, (u64*)cnt, (u64)(d->T / 2));
+            if (d->T & 1) HIPCHK(hipMemsetAsync(cnt + d->T - 1, 0, sizeof(u32), d->stream));
+        } else {
         HIPCHK(hipMemsetAsync(d->slots, 0, d->T * sizeof(u64), d->stream));
         HIPCHK(hipMemsetAsync(cnt, 0, d->T * sizeof(u32), d->stream));
+        }
         HIPCHK(hipMemsetAsync(d->d_counters + 8, 0, 5 * sizeof(u64), d->stream));
         const unsigned gE = (unsigned)std::min<u64>(grid_for(4 * N, 256), 256 * 64);
-        hipLaunchKernelGGL(k_index_count, dim3(gE), dim3(256), 0, d->stream, d->reads, N, d->S, d->h, d->seed, d->slots, d->T, cnt, where);
+        u64* dbgk = nullptr;
+        if (getenv("SAGE2OV_DBG_WHERE")) HIPCHK(hipMalloc(&dbgk, 16 * N * sizeof(u64)));
+        hipLaunchKernelGGL(k_index_count, dim3(gE), dim3(256), 0, d->stream, d->reads, N, d->S, d->h, d->seed, d->slots, d->T, cnt, where, dbgk);
+        if (dbgk) { HIPCHK(hipStreamSynchronize(d->stream)); d->dbg_keys.resize(16 * N); HIPCHK(hipMemcpy(d->dbg_keys.data(), dbgk, 16 * N * sizeof(u64), hipMemcpyDeviceToHost)); hipFree(dbgk); }
         hipLaunchKernelGGL(k_index_alloc, dim3(grid_for(d->T, 256)), dim3(256), 0, d->stream, d->slots, d->T, cnt, d->d_counters + 8, big, big_cap);
         hipLaunchKernelGGL(k_index_fill, dim3(gE), dim3(256), 0, d->stream, N, d->slots, cnt, where, d->csr);
         hipLaunchKernelGGL(k_index_sort, dim3(grid_for(d->T, 256)), dim3(256), 0, d->stream, d->slots, d->T, d->csr);
@@ -683,6 +730,7 @@ int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t
     HIPCHK(hipEventRecord(d->ev[1], d->stream));
     HIPCHK(hipStreamSynchronize(d->stream));
     float ms = 0; hipEventElapsedTime(&ms, d->ev[0], d->ev[1]); d->tm.index_ms += ms;
+    if (getenv("SAGE2OV_DBG_WHERE")) { d->dbg_where.resize(4 * N); HIPCHK(hipMemcpy(d->dbg_where.data(), where, 4 * N * sizeof(u32), hipMemcpyDeviceToHost)); }
     hipFree(cnt); hipFree(where); hipFree(big);
     *slots_out = d->T; *keys_out = d->n_keys; *csr_out = d->n_csr; *nlong_out = d->n_long;
     return 0;
@@ -903,6 +951,43 @@ int dev_unresolved_ids(Device* d, std::vector<uint32_t>& ids, std::string& err) 
         hipFree(buf); cap = cnt;
     }
     err = "unresolved id collection failed"; return SAGE2OV_ERR_INTERNAL;
+}
+
+int dev_debug_table(Device* d, uint64_t* out5, std::string& err) {
+    HIPCHK(hipSetDevice(d->ordinal));
+    u64* dk = nullptr; HIPCHK(hipMalloc(&dk, 8 * sizeof(u64))); HIPCHK(hipMemsetAsync(dk, 0, 8 * sizeof(u64), d->stream));
+    hipLaunchKernelGGL(k_debug_table, dim3(grid_for(d->T, 256)), dim3(256), 0, d->stream, d->slots, (u64)d->T, dk);
+    HIPCHK(hipStreamSynchronize(d->stream));
+    HIPCHK(hipMemcpy(out5, dk, 5 * sizeof(u64), hipMemcpyDeviceToHost)); hipFree(dk); return 0;
+}
+int dev_debug_where(Device* d, uint32_t* out) { if (d->dbg_where.empty()) return SAGE2OV_ERR_ARG; memcpy(out, d->dbg_where.data(), d->dbg_where.size() * 4); return 0; }
+int dev_debug_countkeys(Device* d, uint64_t* out) { if (d->dbg_keys.empty()) return SAGE2OV_ERR_ARG; memcpy(out, d->dbg_keys.data(), d->dbg_keys.size() * 8); return 0; }
+int dev_debug_keys(Device* d, uint64_t* out, std::string& err) {
+    HIPCHK(hipSetDevice(d->ordinal));
+    u64* dk = nullptr; HIPCHK(hipMalloc(&dk, 8 * d->N * sizeof(u64)));
+    hipLaunchKernelGGL(k_debug_keys, dim3(grid_for(4 * d->N, 256)), dim3(256), 0, d->stream, d->reads, (u64)d->N, d->S, d->h, dk);
+    HIPCHK(hipStreamSynchronize(d->stream));
+    HIPCHK(hipMemcpy(out, dk, 8 * d->N * sizeof(u64), hipMemcpyDeviceToHost));
+    hipFree(dk); return 0;
+}
+// diagnostic: hit lists (economyGraph.cpp:591-633 semantics) of EVERY read, as if all were unresolved
+int dev_debug_all_hits(Device* d, std::vector<Hit>& hits, std::string& err) {
+    HIPCHK(hipSetDevice(d->ordinal));
+    const u64 N = d->N; uint8_t* saved = nullptr;
+    HIPCHK(hipMalloc(&saved, N + 1)); HIPCHK(hipMemcpy(saved, d->status, N + 1, hipMemcpyDeviceToDevice));
+    HIPCHK(hipMemset(d->status, 0, N + 1));
+    u64 cap = std::max<u64>(1 << 16, N * 128); Hit* dh = nullptr;
+    HIPCHK(hipMalloc(&dh, cap * sizeof(Hit)));
+    HIPCHK(hipMemsetAsync(d->d_counters + 4, 0, sizeof(u64), d->stream));
+    ProbeArgs A = base_args(d); A.lo = 1; A.hi = N + 1; A.hits = dh; A.hits_cap = cap;
+    int rc = launch_probe<1>(d, A, err);
+    u64 nh = 0;
+    if (!rc) { HIPCHK(hipMemcpyAsync(&nh, d->d_counters + 4, sizeof nh, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream)); }
+    if (!rc && nh > cap) { err = "debug hit buffer too small"; rc = SAGE2OV_ERR_LIMIT; }
+    if (!rc) { hits.resize(nh); if (nh) HIPCHK(hipMemcpy(hits.data(), dh, nh * sizeof(Hit), hipMemcpyDeviceToHost)); }
+    HIPCHK(hipMemcpy(d->status, saved, N + 1, hipMemcpyDeviceToDevice));
+    hipFree(saved); hipFree(dh);
+    return rc;
 }
 
 int dev_append_edges(Device* d, const EdgeCand* e, uint64_t n, std::string& err) {

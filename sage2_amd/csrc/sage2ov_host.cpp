@@ -532,6 +532,20 @@ int sage2ov_overlap_reduce(sage2ov_ctx* c) {
     c->reduced = true; c->converted = false; return SAGE2OV_OK;
 }
 
+int sage2ov_debug_table(sage2ov_ctx* c, uint64_t* out5) { if (!c || !out5 || !c->dev || !c->indexBuilt) return SAGE2OV_ERR_ARG; return dev_debug_table(c->dev, out5, c->err); }
+int sage2ov_debug_where(sage2ov_ctx* c, uint32_t* out) { if (!c || !out || !c->dev) return SAGE2OV_ERR_ARG; return dev_debug_where(c->dev, out); }
+int sage2ov_debug_countkeys(sage2ov_ctx* c, uint64_t* out) { if (!c || !out || !c->dev) return SAGE2OV_ERR_ARG; return dev_debug_countkeys(c->dev, out); }
+int sage2ov_debug_keys(sage2ov_ctx* c, uint64_t* out) { if (!c || !out || !c->dev || !c->organized) return SAGE2OV_ERR_ARG; return dev_debug_keys(c->dev, out, c->err); }
+// diagnostic (tests/tools): every read's verified hits as 5 x u32 rows {from, to, type, len, seq}, sorted by (from, seq)
+int sage2ov_debug_all_hits(sage2ov_ctx* c, uint32_t* out, uint64_t cap_rows, uint64_t* n_rows) {
+    if (!c || !n_rows) return SAGE2OV_ERR_ARG; if (!c->reciprocalDone) return c->fail(SAGE2OV_ERR_ARG, "run the initial pass first");
+    std::vector<Hit> hits; int rc = dev_debug_all_hits(c->dev, hits, c->err); if (rc) return rc;
+    std::sort(hits.begin(), hits.end(), [](const Hit& a, const Hit& b) { return a.from != b.from ? a.from < b.from : a.seq < b.seq; });
+    *n_rows = hits.size();
+    if (out) { if (cap_rows < hits.size()) return c->fail(SAGE2OV_ERR_ARG, "buffer too small");
+        for (size_t x = 0; x < hits.size(); x++) { out[5 * x] = hits[x].from; out[5 * x + 1] = hits[x].to; out[5 * x + 2] = hits[x].type; out[5 * x + 3] = (uint32_t)hits[x].len; out[5 * x + 4] = hits[x].seq; } }
+    return SAGE2OV_OK;
+}
 int sage2ov_overlap_convert(sage2ov_ctx* c) {
     if (!c) return SAGE2OV_ERR_ARG; if (!c->reduced) return c->fail(SAGE2OV_ERR_ARG, "run the reduce phase first");
     uint64_t nf = 0; int rc = dev_convert(c->dev, &nf, c->err); if (rc) return rc;
@@ -578,6 +592,7 @@ int sage2ov_run_steps23(sage2ov_ctx* c) {
     c->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return SAGE2OV_OK;
 }
+int sage2ov_timings_reset(sage2ov_ctx* c) { if (!c) return SAGE2OV_ERR_ARG; if (c->dev) dev_reset_timings(c->dev); c->reduce_ms = 0; c->total_ms = 0; return SAGE2OV_OK; }
 int sage2ov_timings_get(const sage2ov_ctx* c, sage2ov_timings* o) {
     if (!c || !o) return SAGE2OV_ERR_ARG;
     DevTimings t; if (c->dev) dev_timings(c->dev, &t);

@@ -62,6 +62,11 @@ int dev_download_status(Device* d, std::vector<uint8_t>& status, std::string& er
 int dev_unresolved_ids(Device* d, std::vector<uint32_t>& ids, std::string& err);          // ascending
 int dev_collect_reduce_edges(Device* d, std::vector<EdgeCand>& out, std::string& err);
 // append host-computed edge candidates (from the reduce replay) to the device candidate list
+int dev_debug_table(Device* d, uint64_t* out5, std::string& err);
+int dev_debug_where(Device* d, uint32_t* out);
+int dev_debug_countkeys(Device* d, uint64_t* out);
+int dev_debug_keys(Device* d, uint64_t* out, std::string& err);
+int dev_debug_all_hits(Device* d, std::vector<Hit>& hits, std::string& err);
 int dev_append_edges(Device* d, const EdgeCand* e, uint64_t n, std::string& err);
 // sortEconomyGraph + convertGraph: canonical list
 int dev_convert(Device* d, uint64_t* n_final, std::string& err);     // result stays in HBM

@@ -75,6 +75,7 @@ def run_steps23_sharded(ctx, device, group=None):
     complete canonical edge list."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     n = ctx.reads_stats().unique_reads
+    ctx.timings_reset()
     ctx.index_build()
     ctx.overlap_probe_shard()
     ms = max_shard(n, world)

@@ -30,7 +30,7 @@ def lib():
 
 
 COUNTERS = ["N", "good_reads", "total_reads", "total_bp", "avg_len", "n_ov", "contained", "contained_size", "edges_inserted",
-            "transitive_removed", "edges", "long_buckets", "M", "stride", "h"]
+            "transitive_removed", "edges", "long_buckets", "M", "stride", "h", "keys"]
 
 
 class Oracle:
@@ -83,6 +83,11 @@ class Oracle:
         if n:
             lib().orc_export_edges(self.h, C.c_void_p(e.ctypes.data))
         return e
+
+    def debug_hits(self, r1, cap=20000):
+        out = np.zeros((cap, 3), dtype=np.int64)
+        n = lib().orc_debug_hits(self.h, C.c_uint64(int(r1)), C.c_void_p(out.ctypes.data), cap)
+        return out[:min(n, cap)]
 
     def lookup(self, v0, v1, cap=128):
         ent = (C.c_uint64 * cap)()

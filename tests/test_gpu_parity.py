@@ -121,3 +121,33 @@ def test_roundtrip_reads_file_and_tiny_inputs(tmp_path):
     g = s2.Context(21); g.reads_add_ascii(np.zeros(0, np.uint8), np.zeros(1, np.uint64)); g.reads_organize(); g.run_steps23()
     assert len(g.edges()) == 0
     g.close()
+
+
+@pytest.mark.parametrize("pd,k", [
+    (dict(seed=1002, genome_len=300000, n_reads=100000, read_len=150), 40),
+    (dict(seed=1003, genome_len=160000, n_reads=80000, read_len=100, err_ppm=1500, n_repeat_families=3, repeat_copies=6, repeat_len=400), 21),
+])
+def test_scale_100k_matches_oracle_and_is_deterministic(pd, k):
+    """Waves process several reads each and the table is built under real contention at this size (the golden
+    fixtures are too small for either); results must still be bit-identical to the oracle, run after run."""
+    bases, off = fx.make_reads(pd)
+    m = dict(k=k)
+    o = run_oracle(m, bases, off)
+    oe = o.export_edges()
+    prev = None
+    for rep in range(3):
+        g = run_gpu(m, bases, off)
+        assert g.index_stats().keys == o.counter("keys")
+        assert g.overlap_stats().verified_overlaps == o.counter("n_ov")
+        gr, gl, gs, gc = g.overlap_export_initial(); orr, orl, ors, orc = o.export_initial()
+        assert np.array_equal(gc, orc) and np.array_equal(gr[1:], orr[1:]) and np.array_equal(gl[1:], orl[1:])
+        e = g.edges()
+        assert len(e) == len(oe) and np.array_equal(e["from"], oe[:, 0]) and np.array_equal(e["to"], oe[:, 1])
+        assert np.array_equal(e["type"], oe[:, 2]) and np.array_equal(e["length"], oe[:, 3]) and np.array_equal(e["length_twin"], oe[:, 4])
+        st = g.overlap_stats()
+        assert (st.edges_inserted, st.transitive_removed) == (o.counter("edges_inserted"), o.counter("transitive_removed"))
+        cur = e.tobytes()
+        assert prev is None or cur == prev
+        prev = cur
+        g.close()
+    o.close()

@@ -1,8 +1,9 @@
 import sys, os
 R=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, R+'/tests')
 import fixtures as fx, sage2_amd as s2, oracle_lib as ol, numpy as np
+import json
 name = sys.argv[1] if len(sys.argv) > 1 else "g5_mixedlen_k21"
-m = fx.golden(name)
+m = json.loads(name) if name.startswith("{") else fx.golden(name)
 bases, off = fx.make_reads(m["synth"])
 ctx = s2.Context(m["k"]); ctx.reads_add_ascii(bases, off); ctx.reads_organize(); ctx.run_steps23()
 o = ol.Oracle(m["k"], 8); o.add_reads_ascii(bases, off); o.organize(); o.run_all()
