@@ -51,8 +51,12 @@ def cpu_baseline(args, s2, fx):
     cov = args.reads * args.read_len / args.genome
     pd = dict(seed=args.seed + 1000, genome_len=int(n * args.read_len / cov), n_reads=n, read_len=args.read_len)
     p = fx.synth_params(pd)
-    cores = os.cpu_count() or 1
-    threads = min(cores, args.cpu_threads) if args.cpu_threads else cores
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        cores = os.cpu_count() or 1
+    # the GPU box gives one GPU's job a 16-core share of the host (more OpenMP threads only oversubscribe it)
+    threads = args.cpu_threads if args.cpu_threads else min(cores, 16)
     sample = f"{n} x {args.read_len} bp reads, k={args.k}, {pd['genome_len']} bp genome, seed {pd['seed']} (same coverage as the GPU workload)"
     tmp = tempfile.mkdtemp(prefix="sage2bench_")
     out = None
@@ -103,6 +107,24 @@ def cpu_baseline(args, s2, fx):
     return out
 
 
+def cpu_baseline_subprocess(args):
+    """Run cpu_baseline() in a fresh interpreter (no torch, its own OpenMP runtime): the reference's objects and
+    torch's bundled runtimes are kept apart, and a crash in the CPU leg cannot take the bench line with it."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", "--reads", str(args.reads), "--read-len", str(args.read_len),
+           "--k", str(args.k), "--genome", str(args.genome), "--seed", str(args.seed), "--cpu-sample-reads", str(args.cpu_sample_reads),
+           "--cpu-threads", str(args.cpu_threads)] + (["--cpu-port"] if args.cpu_port else [])
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+        for line in reversed(r.stdout.decode().splitlines()):
+            if line.startswith("{"):
+                return json.loads(line)
+        log("[bench] cpu baseline worker failed:", r.returncode, r.stderr.decode()[-2000:])
+    except Exception as e:      # noqa
+        log("[bench] cpu baseline worker failed:", repr(e))
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -118,7 +140,14 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--cpu-port", action="store_true", help="time the CPU restatement instead of oracle/_ref")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    if args.cpu_baseline_worker:
+        import fixtures as fx
+        import sage2_amd as s2
+        print(json.dumps(cpu_baseline(args, s2, fx)), flush=True)
+        return
 
     import numpy as np
     import torch
@@ -232,7 +261,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             ctx.close()
-            res["cpu_baseline"] = cpu_baseline(args, s2, fx)
+            res["cpu_baseline"] = cpu_baseline_subprocess(args)
             if res["cpu_baseline"]:
                 res["speedup_vs_cpu_baseline"] = value / res["cpu_baseline"]["value"]
         print(json.dumps(res), flush=True)
