@@ -182,6 +182,7 @@ typedef struct sage2ov_timings {
     double index_ms, probe_ms, reciprocal_ms, reduce_ms, convert_ms, total_ms;
     double probe_kernel_ms;      /* the dominant kernel alone (HIP events on the context stream) */
     uint64_t probe_kernel_launches;
+    uint64_t sequential_reads;   /* reads the fast kernel handed to the sequential state-machine kernel */
 } sage2ov_timings;
 int sage2ov_timings_get(const sage2ov_ctx* ctx, sage2ov_timings* out);
 int sage2ov_timings_reset(sage2ov_ctx* ctx);

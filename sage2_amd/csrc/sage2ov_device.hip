@@ -186,24 +186,37 @@ __global__ void k_debug_keys(const u64* __restrict__ reads, u64 N, int S, int h,
     u64 hi, lo; entry_key(reads, S, h, (e >> 2) + 1, (int)(e & 3), hi, lo);
     out[2 * e] = hi; out[2 * e + 1] = lo;
 }
+__device__ __forceinline__ u32 block_excl_scan(u32 v, u32* sh, u32& total);
 // counters: [0] csr total, [1] occupied slots, [2] number of big buckets, [3] impurity flag, [4] pure long buckets
-__global__ void k_index_alloc(u64* slots, u64 T, const u32* __restrict__ cnt, u64* counters, u64* big, u32 big_cap) {
-    u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    u32 c = idx < T ? cnt[idx] : 0;
-    u32 need = c >= 2 ? c : 0;
-    // wave-aggregated allocation of CSR space
-    u32 incl = wave_incl_scan(need); u32 tot = __shfl(incl, 63);
-    u64 base = 0;
-    if (tot) { if (lane_id() == 63) base = atomicAdd(&counters[0], (u64)tot); base = __shfl(base, 63); }
-    u64 occ = __ballot(c != 0);
-    if (lane_id() == 0 && occ) atomicAdd(&counters[1], (u64)__popcll(occ));
-    if (c >= 2) {
-        u64 start = base + incl - need;
-        u32 c7 = c >= HASH_THRESHOLD ? SLOT_CNT_LONG : c;
-        slots[idx] = (slots[idx] & (~0ull << SLOT_TAG_SHIFT)) | ((u64)c7 << SLOT_CNT_SHIFT) | start;
-        if (c >= HASH_THRESHOLD) {
-            u64 b = atomicAdd(&counters[2], 1ull);
-            if (b < big_cap) { big[3 * b] = idx; big[3 * b + 1] = start; big[3 * b + 2] = c; }
+// One block owns ALLOC_ITEMS consecutive slots and draws its CSR space with ONE atomic (a per-wave atomic on
+// the same word serialises: 25 ms for 68 M slots; this form streams at HBM speed).
+constexpr int ALLOC_PER_THREAD = 16, ALLOC_ITEMS = 256 * ALLOC_PER_THREAD;
+__global__ __launch_bounds__(256) void k_index_alloc(u64* slots, u64 T, const u32* __restrict__ cnt, u64* counters, u64* big, u32 big_cap) {
+    __shared__ u32 sh[4]; __shared__ u64 shBase;
+    const u64 base0 = (u64)blockIdx.x * ALLOC_ITEMS;
+    u32 c[ALLOC_PER_THREAD]; u32 need = 0, occ = 0;
+#pragma unroll
+    for (int x = 0; x < ALLOC_PER_THREAD; x++) {
+        const u64 idx = base0 + (u64)x * 256 + threadIdx.x;
+        c[x] = idx < T ? cnt[idx] : 0u;
+        need += c[x] >= 2 ? c[x] : 0u; occ += c[x] != 0;
+    }
+    u32 total; u32 excl = block_excl_scan(need, sh, total);
+    u32 occTotal; block_excl_scan(occ, sh, occTotal);
+    if (threadIdx.x == 0) { shBase = total ? atomicAdd(&counters[0], (u64)total) : 0ull; if (occTotal) atomicAdd(&counters[1], (u64)occTotal); }
+    __syncthreads();
+    u64 start = shBase + excl;
+#pragma unroll
+    for (int x = 0; x < ALLOC_PER_THREAD; x++) {
+        if (c[x] >= 2) {
+            const u64 idx = base0 + (u64)x * 256 + threadIdx.x;
+            const u32 c7 = c[x] >= HASH_THRESHOLD ? SLOT_CNT_LONG : c[x];
+            slots[idx] = (slots[idx] & (~0ull << SLOT_TAG_SHIFT)) | ((u64)c7 << SLOT_CNT_SHIFT) | start;
+            if (c[x] >= HASH_THRESHOLD) {
+                u64 b = atomicAdd(&counters[2], 1ull);
+                if (b < big_cap) { big[3 * b] = idx; big[3 * b + 1] = start; big[3 * b + 2] = c[x]; }
+            }
+            start += c[x];
         }
     }
 }
@@ -333,6 +346,8 @@ struct ProbeArgs {
     u64 lo, hi;                    // read id range [lo, hi)
     u64* right; u64* left; u32* conn; u32* cflag;         // MODE 0 outputs
     const uint8_t* status; Hit* hits; u64 hits_cap; u64* counters;   // MODE 1
+    const u32* ids; u64 n_ids;                             // optional explicit read list (replaces [lo,hi))
+    u32* slow; u64 slow_cap;                               // fast kernel: reads handed to the sequential kernel (count in counters[6])
 };
 
 template <int S, int MODE, int WPB>
@@ -344,7 +359,9 @@ __global__ __launch_bounds__(64 * WPB) void k_probe(ProbeArgs A) {
     const int k = A.k, h = A.h;
     if (lane <= 64 - 1) W.y[S][lane] = 0;
 
-    for (u64 i = A.lo + wave0; i < A.hi; i += nwaves) {
+    const u64 first = A.ids ? 0 : A.lo, last = A.ids ? A.n_ids : A.hi;
+    for (u64 it = first + wave0; it < last; it += nwaves) {
+        const u64 i = A.ids ? (u64)A.ids[it] : it;
         if (MODE == 1) { if (A.status[i] != 0) continue; }
         // ---- stage the read and its reverse complement in LDS
         wave_sync();
@@ -526,6 +543,277 @@ __global__ __launch_bounds__(64 * WPB) void k_probe(ProbeArgs A) {
     }
 }
 
+
+// =============================================================================================
+// FAST probe + verify kernel (the hot kernel).  Same results as k_probe<S,0> for every read whose verified
+// hits are mutually consistent (all right overhangs are prefixes of the longest one, same on the left): then
+// the extension state machine of economyGraph.cpp:95-438 never raises an ambiguity flag and reduces to
+//     right = in the FIRST window with a right hit, the hit with the largest L2 (first in bucket order on ties)
+//     left  = in the LAST  window with a left  hit, the hit with the largest L2 (first in bucket order on ties)
+//     connections = number of verified hits
+// which needs no sequential pass.  Reads that fail the consistency test (or overflow the LDS hit list) are
+// appended to a list and re-done by the sequential kernel.  Work per read, one wavefront:
+//   1. two windows per lane: key -> hash -> open-addressed probe (both probes in flight together)
+//   2. bucket sizes -> wave scan -> up to 128 candidates per batch, two per lane, both gathers in flight
+//   3. overlap verify against fwd/rc of the read (registers vs LDS), hits appended to an LDS list
+//   4. longest-reach hit per side -> the read extended by that hit's overhang, in both orientations, in LDS
+//   5. every hit compared over its whole length against the extended read (consistency)
+// =============================================================================================
+constexpr int FAST_CAP = 128;
+template <int S, int W>
+struct FastLds {
+    u64 x[2][S + 1];              // forward, reverse complement (+ zero pad)
+    u64 e[4][2 * S + 2];          // extended strings XR0, XR1, XL0, XL1
+    u64 m[2][S + 1];              // the two longest-reach hits (contiguous copies)
+    u32 candJ[FAST_CAP], candSrc[FAST_CAP];
+    u32 hitMeta[FAST_CAP];        // t:2 | j:14 | L2:16
+    u32 hitEnt[FAST_CAP];         // id*4+type
+    u64 hitY[W][FAST_CAP];
+};
+// 64 bits of X at bit position p; anything outside [0, 64*nw) reads as zero; p may be negative
+__device__ __forceinline__ u64 xbits(const u64* X, int nw, int p) {
+    const int pp = p < 0 ? 0 : p, sh = pp - p;
+    const int q = pp >> 6, r = pp & 63;
+    const int q0 = q < nw ? q : nw - 1, q1 = q + 1 < nw ? q + 1 : nw - 1;
+    u64 a = X[q0], b = X[q1];
+    a = q < nw ? a : 0ull; b = q + 1 < nw ? b : 0ull;
+    const u64 v = (a << r) | ((b >> 1) >> (63 - r));
+    return sh >= 64 ? 0ull : (v >> sh);
+}
+__device__ __forceinline__ u64 range_mask(int lo, int hi) {   // bases [lo,hi) of a 32-base word, clamped
+    return mask_top(hi) & ~mask_top(lo);
+}
+// Y[b] == X[b + d] for all b in [lo, hi)
+template <int W>
+__device__ __forceinline__ bool cmp_yx(const u64 (&Y)[W], const u64* X, int nwX, int d, int lo, int hi) {
+    u64 diff = 0;
+#pragma unroll
+    for (int c = 0; c < W; c++) diff |= (Y[c] ^ xbits(X, nwX, 2 * (32 * c + d))) & range_mask(lo - 32 * c, hi - 32 * c);
+    return diff == 0;
+}
+// dst (nwD words) = A[aStart .. aStart+lenA) ++ B[bStart .. bStart+lenB); one word per lane
+__device__ __forceinline__ void build_concat(u64* dst, int nwD, u32 lane, const u64* A, int nwA, int aStart, int lenA, const u64* B, int nwB, int bStart, int lenB) {
+    if ((int)lane < nwD) {
+        const int cb = 32 * (int)lane;
+        u64 va = xbits(A, nwA, 2 * (cb + aStart)) & range_mask(0 - cb, lenA - cb);
+        u64 vb = xbits(B, nwB, 2 * (cb - lenA + bStart)) & range_mask(lenA - cb, lenA + lenB - cb);
+        dst[lane] = va | vb;
+    }
+}
+// dst = reverse complement of src[0..len)
+__device__ __forceinline__ void build_rc(u64* dst, int nwD, u32 lane, const u64* src, int nwS, int len) {
+    if ((int)lane < nwD) {
+        const int rem = len - 32 * (int)lane; u64 r;
+        if (rem <= 0) r = 0;
+        else if (rem >= 32) r = ~rev2(xbits(src, nwS, 2 * (rem - 32)));
+        else r = (~rev2(src[0] >> (64 - 2 * rem))) & mask_top(rem);
+        dst[lane] = r;
+    }
+}
+__device__ __forceinline__ u64 wave_min_u64(u64 v) {
+#pragma unroll
+    for (int d = 32; d; d >>= 1) { u64 o = __shfl_xor(v, d); v = o < v ? o : v; }
+    return v;
+}
+
+template <int S, int W, int WPB>
+__global__ __launch_bounds__(64 * WPB) void k_probe_fast(ProbeArgs A) {
+    __shared__ FastLds<S, W> lds_all[WPB];
+    FastLds<S, W>& L = lds_all[threadIdx.x >> 6];
+    const u32 lane = lane_id();
+    const u64 wave0 = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((u64)gridDim.x * blockDim.x) >> 6;
+    const int k = A.k, h = A.h;
+    constexpr int NE = 2 * S + 2;
+
+    for (u64 i = A.lo + wave0; i < A.hi; i += nwaves) {
+        wave_sync();
+        if (lane < S) L.x[0][lane] = A.reads[i * S + lane];
+        if (lane == S) { L.x[0][S] = 0; L.x[1][S] = 0; }
+        wave_sync();
+        const int L1 = (int)(L.x[0][S - 1] & 0xFFFF);
+        if (lane == 0) L.x[0][S - 1] &= ~0xFFFFull;                 // drop the length field from the LDS copy
+        build_rc(L.x[1], S, lane, L.x[0], S + 1, L1);
+        wave_sync();
+        if (lane == 0) L.x[1][S - 1] &= ~0xFFFFull;
+        wave_sync();
+
+        const int nwin = L1 - h + 1;
+        bool slowpath = false;
+        u32 nh = 0;
+        // ---------------------------------------------------------------- windows, 128 per sweep
+        for (int jb = 0; jb < nwin; jb += 128) {
+            // 1. probe two windows per lane, both chains in flight
+            int jj[2]; u64 idx[2], tg[2], sl[2]; bool act[2];
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                jj[q] = jb + 64 * q + (int)lane; act[q] = jj[q] < nwin; sl[q] = 0; idx[q] = 0; tg[q] = 0;
+                if (act[q]) { u64 khi, klo; key_at(L.x[0], S + 1, jj[q], h, khi, klo); u64 hv = hash_key(khi, klo, A.seed); idx[q] = home_of(hv, A.T); tg[q] = tag_of(hv); }
+            }
+            bool pend0 = act[0], pend1 = act[1];
+            while (__any(pend0 || pend1)) {
+                const u64 s0 = A.slots[idx[0]], s1 = A.slots[idx[1]];       // unconditional: idle lanes re-read slot 0
+                if (pend0) { if (s0 == 0 || (s0 >> SLOT_TAG_SHIFT) == tg[0]) { sl[0] = s0; pend0 = false; } else if (++idx[0] == A.T) idx[0] = 0; }
+                if (pend1) { if (s1 == 0 || (s1 >> SLOT_TAG_SHIFT) == tg[1]) { sl[1] = s1; pend1 = false; } else if (++idx[1] == A.T) idx[1] = 0; }
+            }
+            u32 cnt[2], pay[2];
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const u32 c7 = (u32)(sl[q] >> SLOT_CNT_SHIFT) & 127u;
+                cnt[q] = (sl[q] != 0 && c7 != SLOT_CNT_LONG) ? c7 : 0u; pay[q] = (u32)(sl[q] & SLOT_PAY_MASK);
+            }
+            // 2. candidates in batches of up to 128
+            const u32 mine = cnt[0] + cnt[1];
+            const u32 incl = wave_incl_scan(mine), total = __shfl(incl, 63), excl = incl - mine;
+            for (u32 cb = 0; cb < total; cb += FAST_CAP) {
+                wave_sync();
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const u32 base = excl + (q ? cnt[0] : 0u);
+                    for (u32 e = 0; e < cnt[q]; e++) {
+                        const u32 g = base + e;
+                        if (g >= cb && g < cb + FAST_CAP) { L.candJ[g - cb] = (u32)jj[q] | (cnt[q] == 1 ? 0u : 0x80000000u); L.candSrc[g - cb] = cnt[q] == 1 ? pay[q] : pay[q] + e; }
+                    }
+                }
+                wave_sync();
+                const u32 nb = min(total - cb, (u32)FAST_CAP);
+                // gather both candidates of this lane
+                u64 Y[2][W]; u32 ent[2]; int cj[2], L2v[2]; bool gate[2];
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const u32 ci = lane + 64 * q; gate[q] = false; ent[q] = 0; cj[q] = 0; L2v[q] = 0;
+#pragma unroll
+                    for (int c = 0; c < W; c++) Y[q][c] = 0;
+                    if (ci < nb) {
+                        const u32 cjj = L.candJ[ci], src = L.candSrc[ci];
+                        const bool isCsr = (cjj & 0x80000000u) != 0;
+                        const u32 ce = A.csr[isCsr ? src : 0u];                 // unconditional load, discarded for inline entries
+                        ent[q] = isCsr ? ce : src; cj[q] = (int)(cjj & 0x7FFFFFFFu);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const u32 ci = lane + 64 * q;
+                    if (ci < nb) {
+                        const u64 r2 = ent[q] >> 2; const int t = ent[q] & 3;
+                        const bool rightSide = (t == 0 || t == 2);
+                        gate[q] = (r2 != i) && (rightSide ? (cj[q] <= L1 - k) : (cj[q] >= k - h));
+                    }
+                    {   // unconditional gather: gated-off lanes read slot 0 (all zero, always cached)
+                        const u64* yp = A.reads + (gate[q] ? (u64)(ent[q] >> 2) : 0ull) * S;
+#pragma unroll
+                        for (int c = 0; c < W; c++) Y[q][c] = yp[c];
+                        L2v[q] = (int)(yp[S - 1] & 0xFFFF);
+                    }
+                }
+                // 3. verify the overlap region
+                bool isHit[2];
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    isHit[q] = false;
+                    if (gate[q]) {
+                        if (W == S) Y[q][W - 1] &= ~0xFFFFull;
+                        const int t = ent[q] & 3, j = cj[q], L2 = L2v[q];
+                        const bool rightSide = (t == 0 || t == 2);
+                        const int span = rightSide ? (L1 - j) : (j + h);
+                        const bool cont = (L2 <= span); const int n = cont ? L2 : span;
+                        bool eq;
+                        if (t == 0)      eq = cmp_yx<W>(Y[q], L.x[0], S + 1, j, 0, n);
+                        else if (t == 3) eq = cmp_yx<W>(Y[q], L.x[1], S + 1, L1 - j - h, 0, n);
+                        else if (t == 2) eq = cmp_yx<W>(Y[q], L.x[1], S + 1, (L1 - j - n) - (L2 - n), L2 - n, L2);
+                        else             eq = cmp_yx<W>(Y[q], L.x[0], S + 1, (j + h - n) - (L2 - n), L2 - n, L2);
+                        if (eq && cont) atomicOr(&A.cflag[ent[q] >> 2], i > (u64)(ent[q] >> 2) ? 1u : 2u);   // economyGraph.cpp:735
+                        isHit[q] = eq && !cont;
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const u64 hb = __ballot(isHit[q]);
+                    const u32 pos = nh + (u32)__popcll(hb & ((1ull << lane) - 1ull));
+                    if (isHit[q]) {
+                        if (pos < (u32)FAST_CAP) {
+                            L.hitMeta[pos] = (u32)(ent[q] & 3) | ((u32)cj[q] << 2) | ((u32)L2v[q] << 16); L.hitEnt[pos] = ent[q];
+#pragma unroll
+                            for (int c = 0; c < W; c++) L.hitY[c][pos] = Y[q][c];
+                        }
+                    }
+                    nh += (u32)__popcll(hb);
+                }
+                if (nh > (u32)FAST_CAP) slowpath = true;
+            }
+        }
+        wave_sync();
+        // ---------------------------------------------------------------- 4. selection and longest reach per side
+        u64 selR = ~0ull, selL = ~0ull, reachR = ~0ull, reachL = ~0ull;
+        if (!slowpath) {
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const u32 x = lane + 64 * q;
+                if (x < nh) {
+                    const u32 mt = L.hitMeta[x], en = L.hitEnt[x];
+                    const int t = mt & 3, j = (mt >> 2) & 0x3FFF, L2 = mt >> 16;
+                    if (t == 0 || t == 2) {
+                        selR = min(selR, ((u64)j << 48) | ((u64)(0xFFFF - L2) << 32) | en);
+                        reachR = min(reachR, ((u64)(0xFFFFF - (j + L2)) << 32) | x);
+                    } else {
+                        selL = min(selL, ((u64)(0x3FFF - j) << 48) | ((u64)(0xFFFF - L2) << 32) | en);
+                        reachL = min(reachL, ((u64)(0xFFFFF - (L1 - j - h + L2)) << 32) | x);
+                    }
+                }
+            }
+            selR = wave_min_u64(selR); selL = wave_min_u64(selL); reachR = wave_min_u64(reachR); reachL = wave_min_u64(reachL);
+            // ---- extended strings
+            int LR = 0, LL = 0;
+            if (reachR != ~0ull) {
+                const u32 mx = (u32)reachR; const u32 mt = L.hitMeta[mx]; const int t = mt & 3, jM = (mt >> 2) & 0x3FFF, L2M = mt >> 16;
+                if (lane < W) L.m[0][lane] = L.hitY[lane][mx]; else if (lane <= S) L.m[0][lane] = 0;
+                wave_sync();
+                LR = jM + L2M;
+                if (t == 0) { build_concat(L.e[0], NE, lane, L.x[0], S + 1, 0, jM, L.m[0], S + 1, 0, L2M); wave_sync(); build_rc(L.e[1], NE, lane, L.e[0], NE, LR); }
+                else { build_concat(L.e[1], NE, lane, L.m[0], S + 1, 0, L2M, L.x[1], S + 1, L1 - jM, jM); wave_sync(); build_rc(L.e[0], NE, lane, L.e[1], NE, LR); }
+            }
+            if (reachL != ~0ull) {
+                const u32 mx = (u32)reachL; const u32 mt = L.hitMeta[mx]; const int t = mt & 3, jM = (mt >> 2) & 0x3FFF, L2M = mt >> 16;
+                const int offM = L1 - jM - h;
+                if (lane < W) L.m[1][lane] = L.hitY[lane][mx]; else if (lane <= S) L.m[1][lane] = 0;
+                wave_sync();
+                LL = offM + L2M;
+                if (t == 3) { build_concat(L.e[2], NE, lane, L.x[1], S + 1, 0, offM, L.m[1], S + 1, 0, L2M); wave_sync(); build_rc(L.e[3], NE, lane, L.e[2], NE, LL); }
+                else { build_concat(L.e[3], NE, lane, L.m[1], S + 1, 0, L2M, L.x[0], S + 1, L1 - offM, offM); wave_sync(); build_rc(L.e[2], NE, lane, L.e[3], NE, LL); }
+            }
+            wave_sync();
+            // ---- 5. every hit against the extended read, whole length
+            bool bad = false;
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const u32 x = lane + 64 * q;
+                if (x < nh) {
+                    const u32 mt = L.hitMeta[x]; const int t = mt & 3, j = (mt >> 2) & 0x3FFF, L2 = mt >> 16;
+                    u64 Yh[W];
+#pragma unroll
+                    for (int c = 0; c < W; c++) Yh[c] = L.hitY[c][x];
+                    bool ok;
+                    if (t == 0)      ok = cmp_yx<W>(Yh, L.e[0], NE, j, 0, L2);
+                    else if (t == 2) ok = cmp_yx<W>(Yh, L.e[1], NE, LR - j - L2, 0, L2);
+                    else if (t == 3) ok = cmp_yx<W>(Yh, L.e[2], NE, L1 - j - h, 0, L2);
+                    else             ok = cmp_yx<W>(Yh, L.e[3], NE, LL - (L1 - j - h) - L2, 0, L2);
+                    bad |= !ok;
+                }
+            }
+            if (__any(bad)) slowpath = true;
+        }
+        if (slowpath) {
+            if (lane == 0) { u64 p = atomicAdd(&A.counters[6], 1ull); if (p < A.slow_cap) A.slow[p] = (u32)i; }
+        } else if (lane == 0) {
+            u64 rv = 0, lv = 0;
+            if (selR != ~0ull) { const u32 en = (u32)selR; const int j = (int)(selR >> 48), L2 = 0xFFFF - (int)((selR >> 32) & 0xFFFF);
+                rv = (u64)(en >> 2) | ((u64)((en & 3) == 2 ? 1 : 0) << 40) | ((u64)((u32)(L2 - (L1 - j)) & 0x3FFFFFu) << 42); }
+            if (selL != ~0ull) { const u32 en = (u32)selL; const int j = 0x3FFF - (int)(selL >> 48), L2 = 0xFFFF - (int)((selL >> 32) & 0xFFFF);
+                lv = (u64)(en >> 2) | ((u64)((en & 3) == 3 ? 1 : 0) << 40) | ((u64)((u32)(L2 - j - h) & 0x3FFFFFu) << 42); }
+            A.right[i] = rv; A.left[i] = lv; A.conn[i] = nh;
+        }
+    }
+}
+
 // =============================================================================================
 // reciprocal pass (economyGraph.cpp:455-480), order-independent restatement:
 //   cond(i) does not depend on the serial order; the `exploredReads[x]!=4` test at the time read i
@@ -547,10 +835,17 @@ __global__ void k_recip_cond(u64 N, const u64* __restrict__ right, const u64* __
         }
         status[i] = cond ? 4 : (is6 ? 6 : (over ? 5 : 0));
     }
-    // block reductions of the log counters
+    // block reductions of the log counters: one atomic per counter per block
+    __shared__ u64 red[3][4];
     u64 ov = c; for (int d = 32; d; d >>= 1) ov += __shfl_xor(ov, d);
-    u64 bc = __ballot(cond), b6 = __ballot(is6);
-    if (lane_id() == 0) { if (ov) atomicAdd(&counters[1], ov); if (bc) atomicAdd(&counters[2], (u64)__popcll(bc)); if (b6) atomicAdd(&counters[3], (u64)__popcll(b6)); }
+    const u64 bc = __ballot(cond), b6 = __ballot(is6);
+    const u32 w = threadIdx.x >> 6;
+    if (lane_id() == 0) { red[0][w] = ov; red[1][w] = (u64)__popcll(bc); red[2][w] = (u64)__popcll(b6); }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        u64 t = 0; for (u32 x = 0; x < blockDim.x / 64; x++) t += red[threadIdx.x][x];
+        if (t) atomicAdd(&counters[1 + threadIdx.x], t);
+    }
 }
 __device__ __forceinline__ u32 flip_type(u32 t) { return t == 0 ? 3u : (t == 3 ? 0u : t); }   // utils.cpp:212
 __device__ __forceinline__ void emit_edge(EdgeCand* cand, u64 cap, u64* counters, const u64* reads, int S, u64 u, u64 v, u32 delta, u32 type) {
@@ -711,7 +1006,7 @@ int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t
         if (getenv("SAGE2OV_DBG_WHERE")) HIPCHK(hipMalloc(&dbgk, 16 * N * sizeof(u64)));
         hipLaunchKernelGGL(k_index_count, dim3(gE), dim3(256), 0, d->stream, d->reads, N, d->S, d->h, d->seed, d->slots, d->T, cnt, where, dbgk);
         if (dbgk) { HIPCHK(hipStreamSynchronize(d->stream)); d->dbg_keys.resize(16 * N); HIPCHK(hipMemcpy(d->dbg_keys.data(), dbgk, 16 * N * sizeof(u64), hipMemcpyDeviceToHost)); hipFree(dbgk); }
-        hipLaunchKernelGGL(k_index_alloc, dim3(grid_for(d->T, 256)), dim3(256), 0, d->stream, d->slots, d->T, cnt, d->d_counters + 8, big, big_cap);
+        hipLaunchKernelGGL(k_index_alloc, dim3(grid_for(d->T, ALLOC_ITEMS)), dim3(256), 0, d->stream, d->slots, d->T, cnt, d->d_counters + 8, big, big_cap);
         hipLaunchKernelGGL(k_index_fill, dim3(gE), dim3(256), 0, d->stream, N, d->slots, cnt, where, d->csr);
         hipLaunchKernelGGL(k_index_sort, dim3(grid_for(d->T, 256)), dim3(256), 0, d->stream, d->slots, d->T, d->csr);
         u64 c[5];
@@ -753,7 +1048,7 @@ int dev_lookup(Device* d, uint64_t hi, uint64_t lo, uint64_t* entries, uint32_t 
 
 template <int MODE>
 static int launch_probe(Device* d, ProbeArgs& A, std::string& err) {
-    const u64 nreads = A.hi - A.lo; if (nreads == 0) return 0;
+    const u64 nreads = A.ids ? A.n_ids : A.hi - A.lo; if (nreads == 0) return 0;
     // one wave per read, 4 waves per block (2 for the 16-word layout: LDS); enough blocks to fill
     // 256 CUs several times over, grid-stride beyond
     const unsigned wpb = d->S == 16 ? 2 : 4;
@@ -774,6 +1069,9 @@ static ProbeArgs base_args(Device* d) {
     return A;
 }
 
+template <int S, int W, int WPB>
+static void launch_fast(Device* d, ProbeArgs& A, unsigned blocks) { hipLaunchKernelGGL((k_probe_fast<S, W, WPB>), dim3(blocks), dim3(64 * WPB), 0, d->stream, A); }
+
 int dev_probe(Device* d, uint64_t lo, uint64_t hi, std::string& err) {
     HIPCHK(hipSetDevice(d->ordinal));
     if (!d->slots) { err = "index not built"; return SAGE2OV_ERR_ARG; }
@@ -781,14 +1079,44 @@ int dev_probe(Device* d, uint64_t lo, uint64_t hi, std::string& err) {
     HIPCHK(hipEventRecord(d->ev[0], d->stream));
     HIPCHK(hipMemsetAsync(d->right, 0, (N + 1) * sizeof(u64), d->stream)); HIPCHK(hipMemsetAsync(d->left, 0, (N + 1) * sizeof(u64), d->stream));
     HIPCHK(hipMemsetAsync(d->conn, 0, (N + 1) * sizeof(u32), d->stream)); HIPCHK(hipMemsetAsync(d->cflag, 0, (N + 1) * sizeof(u32), d->stream));
+    HIPCHK(hipMemsetAsync(d->d_counters + 6, 0, sizeof(u64), d->stream));
     ProbeArgs A = base_args(d); A.lo = lo; A.hi = hi;
-    HIPCHK(hipEventRecord(d->ev[2], d->stream));
-    int rc = launch_probe<0>(d, A, err); if (rc) return rc;
-    HIPCHK(hipEventRecord(d->ev[3], d->stream));
+    const u64 nreads = hi > lo ? hi - lo : 0;
+    const bool seq_only = getenv("SAGE2OV_SEQUENTIAL_PROBE") != nullptr;
+    u32* slow = nullptr;
+    if (nreads && !seq_only) {
+        HIPCHK(hipMalloc(&slow, nreads * sizeof(u32)));
+        A.slow = slow; A.slow_cap = nreads;
+        const int Wn = (d->maxL + 31) / 32;                                  // words that carry bases
+        const unsigned wpb = 4;
+        const unsigned blocks = (unsigned)std::min<u64>((nreads + wpb - 1) / wpb, 256ull * 64);
+        HIPCHK(hipEventRecord(d->ev[2], d->stream));
+        if (d->S == 4) launch_fast<4, 4, 4>(d, A, blocks);
+        else if (d->S == 8 && Wn <= 5) launch_fast<8, 5, 4>(d, A, blocks);
+        else if (d->S == 8) launch_fast<8, 8, 4>(d, A, blocks);
+        else launch_fast<16, 16, 2>(d, A, (unsigned)std::min<u64>((nreads + 1) / 2, 256ull * 64));
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(d->ev[3], d->stream));
+        u64 nslow = 0;
+        HIPCHK(hipMemcpyAsync(&nslow, d->d_counters + 6, sizeof nslow, hipMemcpyDeviceToHost, d->stream));
+        HIPCHK(hipStreamSynchronize(d->stream));
+        float ms = 0; hipEventElapsedTime(&ms, d->ev[2], d->ev[3]); d->tm.probe_kernel_ms += ms; d->tm.probe_launches++;
+        d->tm.slow_reads += nslow;
+        if (nslow) {                                                          // ambiguous / overflowing reads: sequential state machine
+            ProbeArgs B = base_args(d); B.ids = slow; B.n_ids = nslow;
+            int rc = launch_probe<0>(d, B, err); if (rc) { hipFree(slow); return rc; }
+        }
+    } else if (nreads) {
+        HIPCHK(hipEventRecord(d->ev[2], d->stream));
+        int rc = launch_probe<0>(d, A, err); if (rc) return rc;
+        HIPCHK(hipEventRecord(d->ev[3], d->stream));
+        HIPCHK(hipStreamSynchronize(d->stream));
+        float ms = 0; hipEventElapsedTime(&ms, d->ev[2], d->ev[3]); d->tm.probe_kernel_ms += ms; d->tm.probe_launches++;
+    }
     HIPCHK(hipEventRecord(d->ev[1], d->stream));
     HIPCHK(hipStreamSynchronize(d->stream));
+    if (slow) hipFree(slow);
     float ms = 0; hipEventElapsedTime(&ms, d->ev[0], d->ev[1]); d->tm.probe_ms += ms;
-    hipEventElapsedTime(&ms, d->ev[2], d->ev[3]); d->tm.probe_kernel_ms += ms; d->tm.probe_launches++;
     return 0;
 }
 
