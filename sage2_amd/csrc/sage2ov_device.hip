@@ -87,16 +87,29 @@ __device__ __forceinline__ void rc_key(u64 hi, u64 lo, int h, u64& rhi, u64& rlo
     else if (2 * h < 128) nh &= (1ull << (2 * h - 64)) - 1;
     rhi = nh; rlo = nl;
 }
-__device__ __forceinline__ u64 mix64(u64 z) {
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
+// ---- hashing: the key is taken LEFT aligned as four big-endian dwords k0..k3 (2h bits, rest zero) and mixed with
+// rotate/add/xor only (Bob Jenkins' lookup3 final mix): full-rate 32-bit VALU ops, no 64-bit multiplies.
+// The returned pair is (h1 -> home slot by multiply-high with T, h2 -> 24-bit tag).
+__device__ __forceinline__ u32 rotl32(u32 x, int r) { return __builtin_amdgcn_alignbit(x, x, 32 - r); }
+#define S2_FINAL(a, b, c) { c ^= b; c -= rotl32(b, 14); a ^= c; a -= rotl32(c, 11); b ^= a; b -= rotl32(a, 25); c ^= b; c -= rotl32(b, 16); \
+                            a ^= c; a -= rotl32(c, 4); b ^= a; b -= rotl32(a, 14); c ^= b; c -= rotl32(b, 24); }
+__device__ __forceinline__ u64 hash4(u32 k0, u32 k1, u32 k2, u32 k3, u32 seed) {
+    u32 a = 0xdeadbeefu + seed + k0, b = 0x9e3779b9u + k1, c = 0x7f4a7c15u + k2;
+    S2_FINAL(a, b, c);
+    a += k3;
+    S2_FINAL(a, b, c);
+    return ((u64)c << 32) | b;
 }
-__device__ __forceinline__ u64 hash_key(u64 hi, u64 lo, u64 seed) {
-    return mix64((lo + seed) ^ mix64(hi + 0x9E3779B97F4A7C15ull));
+// (hi,lo) = right-aligned 2h-bit key (the integer of utils.cpp:171-187) -> same hash as the left-aligned dwords
+__device__ __forceinline__ u64 hash_key(u64 hi, u64 lo, int h, u64 seed) {
+    const int sh = 128 - 2 * h; u64 nh, nl;
+    if (sh >= 64) { nh = sh == 64 ? lo : (lo << (sh - 64)); nl = 0; }
+    else if (sh == 0) { nh = hi; nl = lo; }
+    else { nh = (hi << sh) | (lo >> (64 - sh)); nl = lo << sh; }
+    return hash4((u32)(nh >> 32), (u32)nh, (u32)(nl >> 32), (u32)nl, (u32)seed);
 }
 __device__ __forceinline__ u32 tag_of(u64 hv) { u32 t = (u32)(hv & 0xFFFFFFu); return t ? t : 1u; }
-__device__ __forceinline__ u64 home_of(u64 hv, u64 T) { return __umul64hi(hv, T); }
+__device__ __forceinline__ u64 home_of(u64 hv, u64 T) { return (u64)__umulhi((u32)(hv >> 32), (u32)T); }
 
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -141,7 +154,7 @@ __global__ void k_index_count_v(const u64* __restrict__ reads, u64 N, int S, int
     const u64 stride = (u64)gridDim.x * blockDim.x;
     for (; e < 4 * N; e += stride) {
         u64 hi, lo; entry_key(reads, S, h, (e >> 2) + 1, (int)(e & 3), hi, lo);
-        u64 hv = hash_key(hi, lo, seed); const u64 tag = tag_of(hv); u64 idx = home_of(hv, T);
+        u64 hv = hash_key(hi, lo, h, seed); const u64 tag = tag_of(hv); u64 idx = home_of(hv, T);
         for (;;) {
             u64 old = atomicCAS((u64*)&slots[idx], 0ull, tag << SLOT_TAG_SHIFT);      // always go through the atomic
             if (old == 0 || (old >> SLOT_TAG_SHIFT) == tag) break;
@@ -156,7 +169,7 @@ __global__ void k_index_count(const u64* __restrict__ reads, u64 N, int S, int h
     const u64 stride = (u64)gridDim.x * blockDim.x;
     for (; e < 4 * N; e += stride) {
         u64 hi, lo; entry_key(reads, S, h, (e >> 2) + 1, (int)(e & 3), hi, lo);
-        u64 hv = hash_key(hi, lo, seed); const u64 tag = tag_of(hv); u64 idx = home_of(hv, T);
+        u64 hv = hash_key(hi, lo, h, seed); const u64 tag = tag_of(hv); u64 idx = home_of(hv, T);
         if (dbg) { dbg[4 * e] = hi; dbg[4 * e + 1] = lo; dbg[4 * e + 2] = hv; dbg[4 * e + 3] = idx; }
         for (;;) {
             u64 s = __hip_atomic_load(&slots[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -251,8 +264,8 @@ __global__ void k_index_purity(const u64* __restrict__ reads, int S, int h, cons
     if (__ballot(bad)) { if (lane_id() == 0) atomicAdd(&counters[3], 1ull); }
     else if (lane_id() == 0) atomicAdd(&counters[4], 1ull);
 }
-__global__ void k_lookup(const u64* __restrict__ slots, u64 T, const u32* __restrict__ csr, u64 seed, u64 hi, u64 lo, u64* out, u32 cap) {
-    u64 s = table_find(slots, T, hash_key(hi, lo, seed));
+__global__ void k_lookup(const u64* __restrict__ slots, u64 T, const u32* __restrict__ csr, u64 seed, int h, u64 hi, u64 lo, u64* out, u32 cap) {
+    u64 s = table_find(slots, T, hash_key(hi, lo, h, seed));
     u32 c7 = (u32)(s >> SLOT_CNT_SHIFT) & 127u;
     if (s == 0 || c7 == SLOT_CNT_LONG) { out[0] = 0; return; }
     out[0] = c7;
@@ -393,7 +406,7 @@ __global__ __launch_bounds__(64 * WPB) void k_probe(ProbeArgs A) {
             u32 cnt = 0; u32 pay = 0; bool inl = false;
             if (j < nwin) {
                 u64 khi, klo; key_at(W.x[0], S + 1, j, h, khi, klo);
-                u64 s = table_find(A.slots, A.T, hash_key(khi, klo, A.seed));
+                u64 s = table_find(A.slots, A.T, hash_key(khi, klo, h, A.seed));
                 u32 c7 = (u32)(s >> SLOT_CNT_SHIFT) & 127u;
                 if (s != 0 && c7 != SLOT_CNT_LONG) { cnt = c7; pay = (u32)(s & SLOT_PAY_MASK); inl = (c7 == 1); }
             }
@@ -545,271 +558,328 @@ __global__ __launch_bounds__(64 * WPB) void k_probe(ProbeArgs A) {
 
 
 // =============================================================================================
-// FAST probe + verify kernel (the hot kernel).  Same results as k_probe<S,0> for every read whose verified
-// hits are mutually consistent (all right overhangs are prefixes of the longest one, same on the left): then
-// the extension state machine of economyGraph.cpp:95-438 never raises an ambiguity flag and reduces to
+// FAST probe + verify kernel (the hot kernel), all-32-bit arithmetic.
+// Same results as k_probe<S,0> for every read whose verified hits are mutually consistent (every right
+// overhang is a prefix of the longest one, same on the left): then the extension state machine of
+// economyGraph.cpp:95-438 never raises an ambiguity flag and reduces to
 //     right = in the FIRST window with a right hit, the hit with the largest L2 (first in bucket order on ties)
 //     left  = in the LAST  window with a left  hit, the hit with the largest L2 (first in bucket order on ties)
 //     connections = number of verified hits
-// which needs no sequential pass.  Reads that fail the consistency test (or overflow the LDS hit list) are
-// appended to a list and re-done by the sequential kernel.  Work per read, one wavefront:
-//   1. two windows per lane: key -> hash -> open-addressed probe (both probes in flight together)
-//   2. bucket sizes -> wave scan -> up to 128 candidates per batch, two per lane, both gathers in flight
-//   3. overlap verify against fwd/rc of the read (registers vs LDS), hits appended to an LDS list
-//   4. longest-reach hit per side -> the read extended by that hit's overhang, in both orientations, in LDS
-//   5. every hit compared over its whole length against the extended read (consistency)
+// which needs no sequential pass.  Anything else (an inconsistent hit, more than 128 candidates, a failed
+// speculation) sends the read to the sequential kernel.  One wavefront per read:
+//   1. WPL windows per lane: key (funnel shifts out of LDS) -> lookup3 hash -> open-addressed probes, all
+//      chains of a lane in flight together
+//   2. bucket sizes -> DPP wave scan -> <= 128 candidates, two per lane, both 64-byte gathers in flight
+//   3. speculation: the candidate reaching furthest right (left) is the longest-overhang hit if it verifies;
+//      the read extended by its overhang is written to LDS in both orientations (lanes 0-31 right, 32-63 left)
+//   4. every candidate compared ONCE, over its whole length, with that extended string: the first mismatch
+//      position classifies it as hit+consistent / not a hit / hit but inconsistent
+//   5. DPP wave reductions pick the extension records
 // =============================================================================================
 constexpr int FAST_CAP = 128;
-template <int S, int W>
+template <int S>
 struct FastLds {
-    u64 x[2][S + 1];              // forward, reverse complement (+ zero pad)
-    u64 e[4][2 * S + 2];          // extended strings XR0, XR1, XL0, XL1
-    u64 m[2][S + 1];              // the two longest-reach hits (contiguous copies)
+    u32 xf[2][2 * S + 2];         // forward, reverse complement as big-endian dwords (+ zero pad)
+    u32 e[4][6 * S + 2];          // XR0 = fwd ++ right overhang, XR1 = rc(XR0), XL0 = rc ++ left overhang, XL1 = rc(XL0)
+                                  // (2*maxL bases + NW dwords of read-ahead for first_mismatch)
+    u32 m[2][2 * S + 2];          // the two speculated longest-reach reads
     u32 candJ[FAST_CAP], candSrc[FAST_CAP];
-    u32 hitMeta[FAST_CAP];        // t:2 | j:14 | L2:16
-    u32 hitEnt[FAST_CAP];         // id*4+type
-    u64 hitY[W][FAST_CAP];
 };
-// 64 bits of X at bit position p; anything outside [0, 64*nw) reads as zero; p may be negative
-__device__ __forceinline__ u64 xbits(const u64* X, int nw, int p) {
-    const int pp = p < 0 ? 0 : p, sh = pp - p;
-    const int q = pp >> 6, r = pp & 63;
-    const int q0 = q < nw ? q : nw - 1, q1 = q + 1 < nw ? q + 1 : nw - 1;
-    u64 a = X[q0], b = X[q1];
-    a = q < nw ? a : 0ull; b = q + 1 < nw ? b : 0ull;
-    const u64 v = (a << r) | ((b >> 1) >> (63 - r));
-    return sh >= 64 ? 0ull : (v >> sh);
+__device__ __forceinline__ u32 rev2_32(u32 x) { x = __brev(x); return ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1); }
+__device__ __forceinline__ u32 mask_top32(int nb) { return nb >= 16 ? ~0u : (nb <= 0 ? 0u : (~0u << (32 - 2 * nb))); }
+__device__ __forceinline__ u32 range_mask32(int lo, int hi) { return mask_top32(hi) & ~mask_top32(lo); }
+__device__ __forceinline__ u32 funnel32(u32 a, u32 b, int r) { return (u32)(((((u64)a) << 32) | b) >> (32 - r)); }   // r in [0,31]
+// 32 bits at bit position p >= 0 of a big-endian dword string (caller guarantees D[q+1] is readable)
+__device__ __forceinline__ u32 get32(const u32* D, int p) { const int q = p >> 5; return funnel32(D[q], D[q + 1], p & 31); }
+// same with bounds: anything outside [0, 32*n) reads as zero, p may be negative
+__device__ __forceinline__ u32 get32z(const u32* D, int n, int p) {
+    const int pp = p < 0 ? 0 : p, sh = pp - p, q = pp >> 5;
+    const int q0 = q < n ? q : n - 1, q1 = q + 1 < n ? q + 1 : n - 1;
+    u32 a = D[q0], b = D[q1]; a = q < n ? a : 0u; b = q + 1 < n ? b : 0u;
+    const u32 v = funnel32(a, b, pp & 31);
+    return sh >= 32 ? 0u : (v >> sh);
 }
-__device__ __forceinline__ u64 range_mask(int lo, int hi) {   // bases [lo,hi) of a 32-base word, clamped
-    return mask_top(hi) & ~mask_top(lo);
-}
-// Y[b] == X[b + d] for all b in [lo, hi)
-template <int W>
-__device__ __forceinline__ bool cmp_yx(const u64 (&Y)[W], const u64* X, int nwX, int d, int lo, int hi) {
-    u64 diff = 0;
-#pragma unroll
-    for (int c = 0; c < W; c++) diff |= (Y[c] ^ xbits(X, nwX, 2 * (32 * c + d))) & range_mask(lo - 32 * c, hi - 32 * c);
-    return diff == 0;
-}
-// dst (nwD words) = A[aStart .. aStart+lenA) ++ B[bStart .. bStart+lenB); one word per lane
-__device__ __forceinline__ void build_concat(u64* dst, int nwD, u32 lane, const u64* A, int nwA, int aStart, int lenA, const u64* B, int nwB, int bStart, int lenB) {
-    if ((int)lane < nwD) {
-        const int cb = 32 * (int)lane;
-        u64 va = xbits(A, nwA, 2 * (cb + aStart)) & range_mask(0 - cb, lenA - cb);
-        u64 vb = xbits(B, nwB, 2 * (cb - lenA + bStart)) & range_mask(lenA - cb, lenA + lenB - cb);
-        dst[lane] = va | vb;
-    }
-}
-// dst = reverse complement of src[0..len)
-__device__ __forceinline__ void build_rc(u64* dst, int nwD, u32 lane, const u64* src, int nwS, int len) {
-    if ((int)lane < nwD) {
-        const int rem = len - 32 * (int)lane; u64 r;
-        if (rem <= 0) r = 0;
-        else if (rem >= 32) r = ~rev2(xbits(src, nwS, 2 * (rem - 32)));
-        else r = (~rev2(src[0] >> (64 - 2 * rem))) & mask_top(rem);
-        dst[lane] = r;
-    }
-}
-__device__ __forceinline__ u64 wave_min_u64(u64 v) {
-#pragma unroll
-    for (int d = 32; d; d >>= 1) { u64 o = __shfl_xor(v, d); v = o < v ? o : v; }
+// ---- DPP wave primitives (gfx9 row_shr / row_bcast)
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ u32 dpp_mov(u32 old, u32 v) { return (u32)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROWMASK, 0xF, false); }
+__device__ __forceinline__ u32 wave_incl_scan_dpp(u32 v) {
+    v += dpp_mov<0x111, 0xF>(0, v); v += dpp_mov<0x112, 0xF>(0, v); v += dpp_mov<0x114, 0xF>(0, v); v += dpp_mov<0x118, 0xF>(0, v);
+    v += dpp_mov<0x142, 0xA>(0, v); v += dpp_mov<0x143, 0xC>(0, v);
     return v;
 }
+__device__ __forceinline__ u32 wave_min_dpp(u32 v) {                 // result valid in lane 63, returned broadcast
+    v = min(v, dpp_mov<0x111, 0xF>(~0u, v)); v = min(v, dpp_mov<0x112, 0xF>(~0u, v)); v = min(v, dpp_mov<0x114, 0xF>(~0u, v)); v = min(v, dpp_mov<0x118, 0xF>(~0u, v));
+    v = min(v, dpp_mov<0x142, 0xA>(~0u, v)); v = min(v, dpp_mov<0x143, 0xC>(~0u, v));
+    return (u32)__builtin_amdgcn_readlane((int)v, 63);
+}
 
-template <int S, int W, int WPB>
+// first mismatching base of Y[0..) against E at base offset d (>= 0); NOMATCH when all NW dwords agree
+constexpr int NOMATCH = 1 << 20;
+template <int NW>
+__device__ __forceinline__ int first_mismatch(const u32 (&Y)[NW], const u32* E, int d, int cl, u32 tailMask) {
+    const int q = (2 * d) >> 5, r = (2 * d) & 31;
+    int fm = NOMATCH;
+    u32 nxt = E[q + NW];
+#pragma unroll
+    for (int c = NW - 1; c >= 0; c--) {
+        const u32 cur = E[q + c];
+        u32 diff = Y[c] ^ funnel32(cur, nxt, r);
+        diff &= (c < cl) ? ~0u : (c == cl ? tailMask : 0u);      // bases beyond L2 do not count
+        fm = diff ? 16 * c + (__clz(diff) >> 1) : fm;
+        nxt = cur;
+    }
+    return fm;
+}
+
+template <int S, int NW, int WPL, int WPB>
 __global__ __launch_bounds__(64 * WPB) void k_probe_fast(ProbeArgs A) {
-    __shared__ FastLds<S, W> lds_all[WPB];
-    FastLds<S, W>& L = lds_all[threadIdx.x >> 6];
+    __shared__ FastLds<S> lds_all[WPB];
+    FastLds<S>& L = lds_all[threadIdx.x >> 6];
     const u32 lane = lane_id();
     const u64 wave0 = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((u64)gridDim.x * blockDim.x) >> 6;
     const int k = A.k, h = A.h;
-    constexpr int NE = 2 * S + 2;
+    constexpr int D = 2 * S;                       // dwords per read slot
+    constexpr int ND = 6 * S + 2;                  // dwords per extended string
+    const u32* reads32 = (const u32*)A.reads;
+    const int nk = (2 * h + 31) >> 5;              // key dwords
+    const u32 lastKeyMask = (2 * h) & 31 ? (~0u << (32 - ((2 * h) & 31))) : ~0u;
+    const u32 T32 = (u32)A.T, seed32 = (u32)A.seed;
 
     for (u64 i = A.lo + wave0; i < A.hi; i += nwaves) {
+        // ---------------------------------------------------------------- stage the read (big-endian dwords) + its reverse complement
         wave_sync();
-        if (lane < S) L.x[0][lane] = A.reads[i * S + lane];
-        if (lane == S) { L.x[0][S] = 0; L.x[1][S] = 0; }
+        if (lane < D) L.xf[0][lane] = reads32[i * D + (lane ^ 1)];
+        else if (lane < D + 2) { L.xf[0][lane] = 0; L.xf[1][lane] = 0; }
         wave_sync();
-        const int L1 = (int)(L.x[0][S - 1] & 0xFFFF);
-        if (lane == 0) L.x[0][S - 1] &= ~0xFFFFull;                 // drop the length field from the LDS copy
-        build_rc(L.x[1], S, lane, L.x[0], S + 1, L1);
+        const int L1 = (int)(L.xf[0][D - 1] & 0xFFFFu);
+        if (lane == 0) L.xf[0][D - 1] &= 0xFFFF0000u;
         wave_sync();
-        if (lane == 0) L.x[1][S - 1] &= ~0xFFFFull;
-        wave_sync();
-
-        const int nwin = L1 - h + 1;
-        bool slowpath = false;
-        u32 nh = 0;
-        // ---------------------------------------------------------------- windows, 128 per sweep
-        for (int jb = 0; jb < nwin; jb += 128) {
-            // 1. probe two windows per lane, both chains in flight
-            int jj[2]; u64 idx[2], tg[2], sl[2]; bool act[2];
-#pragma unroll
-            for (int q = 0; q < 2; q++) {
-                jj[q] = jb + 64 * q + (int)lane; act[q] = jj[q] < nwin; sl[q] = 0; idx[q] = 0; tg[q] = 0;
-                if (act[q]) { u64 khi, klo; key_at(L.x[0], S + 1, jj[q], h, khi, klo); u64 hv = hash_key(khi, klo, A.seed); idx[q] = home_of(hv, A.T); tg[q] = tag_of(hv); }
-            }
-            bool pend0 = act[0], pend1 = act[1];
-            while (__any(pend0 || pend1)) {
-                const u64 s0 = A.slots[idx[0]], s1 = A.slots[idx[1]];       // unconditional: idle lanes re-read slot 0
-                if (pend0) { if (s0 == 0 || (s0 >> SLOT_TAG_SHIFT) == tg[0]) { sl[0] = s0; pend0 = false; } else if (++idx[0] == A.T) idx[0] = 0; }
-                if (pend1) { if (s1 == 0 || (s1 >> SLOT_TAG_SHIFT) == tg[1]) { sl[1] = s1; pend1 = false; } else if (++idx[1] == A.T) idx[1] = 0; }
-            }
-            u32 cnt[2], pay[2];
-#pragma unroll
-            for (int q = 0; q < 2; q++) {
-                const u32 c7 = (u32)(sl[q] >> SLOT_CNT_SHIFT) & 127u;
-                cnt[q] = (sl[q] != 0 && c7 != SLOT_CNT_LONG) ? c7 : 0u; pay[q] = (u32)(sl[q] & SLOT_PAY_MASK);
-            }
-            // 2. candidates in batches of up to 128
-            const u32 mine = cnt[0] + cnt[1];
-            const u32 incl = wave_incl_scan(mine), total = __shfl(incl, 63), excl = incl - mine;
-            for (u32 cb = 0; cb < total; cb += FAST_CAP) {
-                wave_sync();
-#pragma unroll
-                for (int q = 0; q < 2; q++) {
-                    const u32 base = excl + (q ? cnt[0] : 0u);
-                    for (u32 e = 0; e < cnt[q]; e++) {
-                        const u32 g = base + e;
-                        if (g >= cb && g < cb + FAST_CAP) { L.candJ[g - cb] = (u32)jj[q] | (cnt[q] == 1 ? 0u : 0x80000000u); L.candSrc[g - cb] = cnt[q] == 1 ? pay[q] : pay[q] + e; }
-                    }
-                }
-                wave_sync();
-                const u32 nb = min(total - cb, (u32)FAST_CAP);
-                // gather both candidates of this lane
-                u64 Y[2][W]; u32 ent[2]; int cj[2], L2v[2]; bool gate[2];
-#pragma unroll
-                for (int q = 0; q < 2; q++) {
-                    const u32 ci = lane + 64 * q; gate[q] = false; ent[q] = 0; cj[q] = 0; L2v[q] = 0;
-#pragma unroll
-                    for (int c = 0; c < W; c++) Y[q][c] = 0;
-                    if (ci < nb) {
-                        const u32 cjj = L.candJ[ci], src = L.candSrc[ci];
-                        const bool isCsr = (cjj & 0x80000000u) != 0;
-                        const u32 ce = A.csr[isCsr ? src : 0u];                 // unconditional load, discarded for inline entries
-                        ent[q] = isCsr ? ce : src; cj[q] = (int)(cjj & 0x7FFFFFFFu);
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < 2; q++) {
-                    const u32 ci = lane + 64 * q;
-                    if (ci < nb) {
-                        const u64 r2 = ent[q] >> 2; const int t = ent[q] & 3;
-                        const bool rightSide = (t == 0 || t == 2);
-                        gate[q] = (r2 != i) && (rightSide ? (cj[q] <= L1 - k) : (cj[q] >= k - h));
-                    }
-                    {   // unconditional gather: gated-off lanes read slot 0 (all zero, always cached)
-                        const u64* yp = A.reads + (gate[q] ? (u64)(ent[q] >> 2) : 0ull) * S;
-#pragma unroll
-                        for (int c = 0; c < W; c++) Y[q][c] = yp[c];
-                        L2v[q] = (int)(yp[S - 1] & 0xFFFF);
-                    }
-                }
-                // 3. verify the overlap region
-                bool isHit[2];
-#pragma unroll
-                for (int q = 0; q < 2; q++) {
-                    isHit[q] = false;
-                    if (gate[q]) {
-                        if (W == S) Y[q][W - 1] &= ~0xFFFFull;
-                        const int t = ent[q] & 3, j = cj[q], L2 = L2v[q];
-                        const bool rightSide = (t == 0 || t == 2);
-                        const int span = rightSide ? (L1 - j) : (j + h);
-                        const bool cont = (L2 <= span); const int n = cont ? L2 : span;
-                        bool eq;
-                        if (t == 0)      eq = cmp_yx<W>(Y[q], L.x[0], S + 1, j, 0, n);
-                        else if (t == 3) eq = cmp_yx<W>(Y[q], L.x[1], S + 1, L1 - j - h, 0, n);
-                        else if (t == 2) eq = cmp_yx<W>(Y[q], L.x[1], S + 1, (L1 - j - n) - (L2 - n), L2 - n, L2);
-                        else             eq = cmp_yx<W>(Y[q], L.x[0], S + 1, (j + h - n) - (L2 - n), L2 - n, L2);
-                        if (eq && cont) atomicOr(&A.cflag[ent[q] >> 2], i > (u64)(ent[q] >> 2) ? 1u : 2u);   // economyGraph.cpp:735
-                        isHit[q] = eq && !cont;
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < 2; q++) {
-                    const u64 hb = __ballot(isHit[q]);
-                    const u32 pos = nh + (u32)__popcll(hb & ((1ull << lane) - 1ull));
-                    if (isHit[q]) {
-                        if (pos < (u32)FAST_CAP) {
-                            L.hitMeta[pos] = (u32)(ent[q] & 3) | ((u32)cj[q] << 2) | ((u32)L2v[q] << 16); L.hitEnt[pos] = ent[q];
-#pragma unroll
-                            for (int c = 0; c < W; c++) L.hitY[c][pos] = Y[q][c];
-                        }
-                    }
-                    nh += (u32)__popcll(hb);
-                }
-                if (nh > (u32)FAST_CAP) slowpath = true;
-            }
+        if (lane < D) {
+            const int rem = L1 - 16 * (int)lane; u32 r;
+            if (rem <= 0) r = 0;
+            else if (rem >= 16) r = ~rev2_32(get32(L.xf[0], 2 * (rem - 16)));
+            else r = (~rev2_32(L.xf[0][0] >> (32 - 2 * rem))) & mask_top32(rem);
+            L.xf[1][lane] = r;
         }
         wave_sync();
-        // ---------------------------------------------------------------- 4. selection and longest reach per side
-        u64 selR = ~0ull, selL = ~0ull, reachR = ~0ull, reachL = ~0ull;
-        if (!slowpath) {
+        const int nwin = L1 - h + 1;
+        bool slowpath = nwin > 64 * WPL;
+
+        // ---------------------------------------------------------------- 1. probes
+        int jj[WPL]; u32 idx[WPL], tg[WPL]; u64 sl[WPL]; bool pend[WPL];
 #pragma unroll
-            for (int q = 0; q < 2; q++) {
-                const u32 x = lane + 64 * q;
-                if (x < nh) {
-                    const u32 mt = L.hitMeta[x], en = L.hitEnt[x];
-                    const int t = mt & 3, j = (mt >> 2) & 0x3FFF, L2 = mt >> 16;
-                    if (t == 0 || t == 2) {
-                        selR = min(selR, ((u64)j << 48) | ((u64)(0xFFFF - L2) << 32) | en);
-                        reachR = min(reachR, ((u64)(0xFFFFF - (j + L2)) << 32) | x);
-                    } else {
-                        selL = min(selL, ((u64)(0x3FFF - j) << 48) | ((u64)(0xFFFF - L2) << 32) | en);
-                        reachL = min(reachL, ((u64)(0xFFFFF - (L1 - j - h + L2)) << 32) | x);
-                    }
+        for (int q = 0; q < WPL; q++) {
+            jj[q] = 64 * q + (int)lane; pend[q] = jj[q] < nwin; sl[q] = 0;
+            const int p = 2 * (pend[q] ? jj[q] : 0);
+            u32 k0 = get32(L.xf[0], p), k1 = nk > 1 ? get32(L.xf[0], p + 32) : 0u, k2 = nk > 2 ? get32(L.xf[0], p + 64) : 0u, k3 = nk > 3 ? get32(L.xf[0], p + 96) : 0u;
+            if (nk == 1) k0 &= lastKeyMask; else if (nk == 2) k1 &= lastKeyMask; else if (nk == 3) k2 &= lastKeyMask; else k3 &= lastKeyMask;
+            const u64 hv = hash4(k0, k1, k2, k3, seed32);
+            idx[q] = __umulhi((u32)(hv >> 32), T32); tg[q] = tag_of(hv);
+        }
+        for (;;) {
+            bool any = false;
+#pragma unroll
+            for (int q = 0; q < WPL; q++) any |= pend[q];
+            if (!__any(any)) break;
+            u64 sv[WPL];
+#pragma unroll
+            for (int q = 0; q < WPL; q++) sv[q] = A.slots[idx[q]];              // unconditional: idle lanes re-read their last slot
+#pragma unroll
+            for (int q = 0; q < WPL; q++) {
+                if (pend[q]) {
+                    if (sv[q] == 0 || (u32)(sv[q] >> SLOT_TAG_SHIFT) == tg[q]) { sl[q] = sv[q]; pend[q] = false; }
+                    else if (++idx[q] == T32) idx[q] = 0;
                 }
             }
-            selR = wave_min_u64(selR); selL = wave_min_u64(selL); reachR = wave_min_u64(reachR); reachL = wave_min_u64(reachL);
-            // ---- extended strings
-            int LR = 0, LL = 0;
-            if (reachR != ~0ull) {
-                const u32 mx = (u32)reachR; const u32 mt = L.hitMeta[mx]; const int t = mt & 3, jM = (mt >> 2) & 0x3FFF, L2M = mt >> 16;
-                if (lane < W) L.m[0][lane] = L.hitY[lane][mx]; else if (lane <= S) L.m[0][lane] = 0;
-                wave_sync();
-                LR = jM + L2M;
-                if (t == 0) { build_concat(L.e[0], NE, lane, L.x[0], S + 1, 0, jM, L.m[0], S + 1, 0, L2M); wave_sync(); build_rc(L.e[1], NE, lane, L.e[0], NE, LR); }
-                else { build_concat(L.e[1], NE, lane, L.m[0], S + 1, 0, L2M, L.x[1], S + 1, L1 - jM, jM); wave_sync(); build_rc(L.e[0], NE, lane, L.e[1], NE, LR); }
-            }
-            if (reachL != ~0ull) {
-                const u32 mx = (u32)reachL; const u32 mt = L.hitMeta[mx]; const int t = mt & 3, jM = (mt >> 2) & 0x3FFF, L2M = mt >> 16;
-                const int offM = L1 - jM - h;
-                if (lane < W) L.m[1][lane] = L.hitY[lane][mx]; else if (lane <= S) L.m[1][lane] = 0;
-                wave_sync();
-                LL = offM + L2M;
-                if (t == 3) { build_concat(L.e[2], NE, lane, L.x[1], S + 1, 0, offM, L.m[1], S + 1, 0, L2M); wave_sync(); build_rc(L.e[3], NE, lane, L.e[2], NE, LL); }
-                else { build_concat(L.e[3], NE, lane, L.m[1], S + 1, 0, L2M, L.x[0], S + 1, L1 - offM, offM); wave_sync(); build_rc(L.e[2], NE, lane, L.e[3], NE, LL); }
+        }
+        // ---------------------------------------------------------------- 2. candidates
+        u32 cnt[WPL], pay[WPL], mine = 0;
+#pragma unroll
+        for (int q = 0; q < WPL; q++) {
+            const u32 c7 = (u32)(sl[q] >> SLOT_CNT_SHIFT) & 127u;
+            cnt[q] = (sl[q] != 0 && c7 != SLOT_CNT_LONG) ? c7 : 0u; pay[q] = (u32)(sl[q] & SLOT_PAY_MASK); mine += cnt[q];
+        }
+        const u32 incl = wave_incl_scan_dpp(mine);
+        const u32 total = (u32)__builtin_amdgcn_readlane((int)incl, 63);
+        if (total > (u32)FAST_CAP) slowpath = true;
+        u32 nhits = 0; u32 selR = ~0u, selL = ~0u;
+        u32 myEnt[2] = {0, 0}; int myJ[2] = {0, 0}, myL2[2] = {0, 0};
+        if (!slowpath) {
+            u32 base = incl - mine;
+#pragma unroll
+            for (int q = 0; q < WPL; q++) {
+                for (u32 e = 0; e < cnt[q]; e++) { L.candJ[base + e] = (u32)jj[q] | (cnt[q] == 1 ? 0u : 0x80000000u); L.candSrc[base + e] = cnt[q] == 1 ? pay[q] : pay[q] + e; }
+                base += cnt[q];
             }
             wave_sync();
-            // ---- 5. every hit against the extended read, whole length
-            bool bad = false;
+            // ---- gather: entry (CSR for multi-entry buckets), then the 64-byte read slot, two candidates per lane
+            u32 Y[2][NW]; bool gate[2];
 #pragma unroll
             for (int q = 0; q < 2; q++) {
-                const u32 x = lane + 64 * q;
-                if (x < nh) {
-                    const u32 mt = L.hitMeta[x]; const int t = mt & 3, j = (mt >> 2) & 0x3FFF, L2 = mt >> 16;
-                    u64 Yh[W];
+                const u32 ci = lane + 64 * q; const bool have = ci < total;
+                const u32 cjj = L.candJ[have ? ci : 0], src = L.candSrc[have ? ci : 0];
+                const bool isCsr = (cjj & 0x80000000u) != 0;
+                const u32 ce = A.csr[(have && isCsr) ? src : 0u];
+                myEnt[q] = isCsr ? ce : src; myJ[q] = (int)(cjj & 0x7FFFFFFFu);
+                const u32 r2 = myEnt[q] >> 2; const int t = myEnt[q] & 3;
+                gate[q] = have && (r2 != (u32)i) && ((t == 0 || t == 2) ? (myJ[q] <= L1 - k) : (myJ[q] >= k - h));
+            }
 #pragma unroll
-                    for (int c = 0; c < W; c++) Yh[c] = L.hitY[c][x];
-                    bool ok;
-                    if (t == 0)      ok = cmp_yx<W>(Yh, L.e[0], NE, j, 0, L2);
-                    else if (t == 2) ok = cmp_yx<W>(Yh, L.e[1], NE, LR - j - L2, 0, L2);
-                    else if (t == 3) ok = cmp_yx<W>(Yh, L.e[2], NE, L1 - j - h, 0, L2);
-                    else             ok = cmp_yx<W>(Yh, L.e[3], NE, LL - (L1 - j - h) - L2, 0, L2);
-                    bad |= !ok;
+            for (int q = 0; q < 2; q++) {
+                const u64* yp = A.reads + (gate[q] ? (u64)(myEnt[q] >> 2) : 0ull) * S;       // gated-off lanes read slot 0 (zeros)
+#pragma unroll
+                for (int c = 0; c < NW / 2; c++) { const u64 w = yp[c]; Y[q][2 * c] = (u32)(w >> 32); Y[q][2 * c + 1] = (u32)w; }
+                myL2[q] = (int)(yp[S - 1] & 0xFFFF);
+                if (NW == D) Y[q][NW - 1] &= 0xFFFF0000u;
+            }
+            // ---------------------------------------------------------------- 3. speculation: furthest reach per side
+            u32 reachR = ~0u, reachL = ~0u;
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                if (gate[q]) {
+                    const int t = myEnt[q] & 3; const u32 ci = lane + 64 * q;
+                    if (t == 0 || t == 2) reachR = min(reachR, ((u32)(0x7FF - (myJ[q] + myL2[q])) << 7) | ci);
+                    else reachL = min(reachL, ((u32)(0x7FF - (L1 - myJ[q] - h + myL2[q])) << 7) | ci);
                 }
             }
-            if (__any(bad)) slowpath = true;
+            reachR = wave_min_dpp(reachR); reachL = wave_min_dpp(reachL);
+            // the two speculated reads verify their overlap and publish themselves; per-side parameters for the builders
+            int LR = 0, LL = 0; bool specFail = false;
+            (void)LR; (void)LL;
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const u32 ci = lane + 64 * q;
+                const bool isMR = reachR != ~0u && (reachR & 127u) == ci, isML = reachL != ~0u && (reachL & 127u) == ci;
+                if (isMR || isML) {
+                    const int t = myEnt[q] & 3, j = myJ[q], L2 = myL2[q];
+                    const int span = isMR ? (L1 - j) : (j + h); const int n = L2 < span ? L2 : span;
+                    // overlap region only: Y[b] == X[b+d] for b in [lo,hi)
+                    const u32* X = (t == 0 || t == 1) ? L.xf[0] : L.xf[1];
+                    int d, lo, hi;
+                    if (t == 0) { d = j; lo = 0; hi = n; } else if (t == 3) { d = L1 - j - h; lo = 0; hi = n; }
+                    else if (t == 2) { d = L1 - j - L2; lo = L2 - n; hi = L2; } else { d = j + h - L2; lo = L2 - n; hi = L2; }
+                    u32 diff = 0;
+#pragma unroll
+                    for (int c = 0; c < NW; c++) diff |= (Y[q][c] ^ get32z(X, D + 2, 2 * (16 * c + d))) & range_mask32(lo - 16 * c, hi - 16 * c);
+                    if (diff != 0 || L2 <= span) specFail = true;       // not a proper overlap: let the sequential kernel sort it out
+                    u32* M = L.m[isMR ? 0 : 1];
+#pragma unroll
+                    for (int c = 0; c < NW; c++) M[c] = Y[q][c];
+#pragma unroll
+                    for (int c = NW; c < D + 2; c++) M[c] = 0;
+                }
+            }
+            if (__any(specFail)) slowpath = true;
+            wave_sync();
+            if (!slowpath) {
+                // ---- extended strings: lanes 0-31 build the right side, lanes 32-63 the left side
+                // (t, j, L2) of the two speculated reads, broadcast with readlane (EXEC independent)
+                u32 mEnt[2] = {0, 0}; int mJ[2] = {0, 0}, mL2[2] = {0, 0};
+#pragma unroll
+                for (int sd = 0; sd < 2; sd++) {
+                    const u32 rk = sd ? reachL : reachR;
+                    if (rk != ~0u) {
+                        const int ol = (int)(rk & 63u); const bool oq = ((rk >> 6) & 1u) != 0;
+                        mEnt[sd] = (u32)__builtin_amdgcn_readlane((int)(oq ? myEnt[1] : myEnt[0]), ol);
+                        mJ[sd] = __builtin_amdgcn_readlane(oq ? myJ[1] : myJ[0], ol);
+                        mL2[sd] = __builtin_amdgcn_readlane(oq ? myL2[1] : myL2[0], ol);
+                    }
+                }
+                LR = reachR != ~0u ? mJ[0] + mL2[0] : 0;
+                LL = reachL != ~0u ? (L1 - mJ[1] - h) + mL2[1] : 0;
+                {
+                    const int side = lane >> 5, c = (int)(lane & 31);
+                    const u32 rk = side ? reachL : reachR;
+                    if (rk != ~0u) {
+                        const int t = (side ? mEnt[1] : mEnt[0]) & 3, L2M = side ? mL2[1] : mL2[0];
+                        const int posM = side ? (L1 - mJ[1] - h) : mJ[0];            // offset of the read in its side's coordinates
+                        const int tot = posM + L2M;
+                        // straight: own strand [0,posM) ++ M ; mirrored: M ++ other strand [L1-posM, L1)
+                        const bool straight = side ? (t == 3) : (t == 0);
+                        const u32* own = side ? L.xf[1] : L.xf[0]; const u32* oth = side ? L.xf[0] : L.xf[1];
+                        u32* dstA = L.e[2 * side + (straight ? 0 : 1)]; u32* dstB = L.e[2 * side + (straight ? 1 : 0)];
+                        const u32* Aa = straight ? own : L.m[side]; const int lenA = straight ? posM : L2M;
+                        const u32* Bb = straight ? L.m[side] : oth; const int bStart = straight ? 0 : (L1 - posM), lenB = straight ? L2M : posM;
+                        for (int cc = c; cc < ND; cc += 32) {
+                            const int cb = 16 * cc;
+                            const u32 va = get32z(Aa, D + 2, 2 * cb) & range_mask32(0 - cb, lenA - cb);
+                            const u32 vb = get32z(Bb, D + 2, 2 * (cb - lenA + bStart)) & range_mask32(lenA - cb, lenA + lenB - cb);
+                            dstA[cc] = va | vb;
+                        }
+                        wave_sync();
+                        for (int cc = c; cc < ND; cc += 32) {
+                            const int rem = tot - 16 * cc; u32 r;
+                            if (rem <= 0) r = 0;
+                            else if (rem >= 16) r = ~rev2_32(get32z(dstA, ND, 2 * (rem - 16)));
+                            else r = (~rev2_32(dstA[0] >> (32 - 2 * rem))) & mask_top32(rem);
+                            dstB[cc] = r;
+                        }
+                    }
+                }
+                wave_sync();
+                // ---------------------------------------------------------------- 4. one whole-length compare per candidate
+                bool bad = false;
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    bool hit = false;
+                    if (gate[q]) {
+                        const int t = myEnt[q] & 3, j = myJ[q], L2 = myL2[q];
+                        const bool rightSide = (t == 0 || t == 2);
+                        const int span = rightSide ? (L1 - j) : (j + h);
+                        const bool cont = L2 <= span; const int n = cont ? L2 : span;
+                        const int off = L1 - j - h;
+                        const u32* E = L.e[t == 0 ? 0 : (t == 2 ? 1 : (t == 3 ? 2 : 3))];
+                        // a contained read (or one reaching past the speculated end: impossible) cannot use the extended string
+                        const int d = t == 0 ? j : (t == 2 ? LR - j - L2 : (t == 3 ? off : LL - off - L2));
+                        const bool usable = !cont && d >= 0;
+                        int fm = NOMATCH;
+                        if (usable) fm = first_mismatch<NW>(Y[q], E, d, L2 >> 4, mask_top32(L2 & 15));
+                        if (usable && fm == NOMATCH) hit = true;                                   // verified and consistent
+                        else {
+                            // rare: decide between "not an overlap" and "overlap, but inconsistent / contained"
+                            const u32* X = (t == 0 || t == 1) ? L.xf[0] : L.xf[1];
+                            int dd, lo, hi;
+                            if (t == 0) { dd = j; lo = 0; hi = n; } else if (t == 3) { dd = off; lo = 0; hi = n; }
+                            else if (t == 2) { dd = L1 - j - L2; lo = L2 - n; hi = L2; } else { dd = j + h - L2; lo = L2 - n; hi = L2; }
+                            u32 diff = 0;
+#pragma unroll
+                            for (int c = 0; c < NW; c++) diff |= (Y[q][c] ^ get32z(X, D + 2, 2 * (16 * c + dd))) & range_mask32(lo - 16 * c, hi - 16 * c);
+                            if (diff == 0) {
+                                if (cont) atomicOr(&A.cflag[myEnt[q] >> 2], i > (u64)(myEnt[q] >> 2) ? 1u : 2u);   // economyGraph.cpp:735
+                                else bad = true;                                                    // a true overlap that disagrees with the longest one
+                            }
+                        }
+                    }
+                    const u64 hb = __ballot(hit);
+                    nhits += (u32)__popcll(hb);
+                    if (hit) {
+                        const int t = myEnt[q] & 3; const u32 ci = lane + 64 * q;
+                        if (t == 0 || t == 2) selR = min(selR, ((u32)myJ[q] << 17) | ((u32)(0x3FF - myL2[q]) << 7) | ci);
+                        else selL = min(selL, ((u32)(0x1FF - myJ[q]) << 17) | ((u32)(0x3FF - myL2[q]) << 7) | ci);
+                    }
+                }
+                if (__any(bad)) slowpath = true;
+            }
         }
         if (slowpath) {
             if (lane == 0) { u64 p = atomicAdd(&A.counters[6], 1ull); if (p < A.slow_cap) A.slow[p] = (u32)i; }
-        } else if (lane == 0) {
+        } else {
+            // ---------------------------------------------------------------- 5. extension records
+            selR = wave_min_dpp(selR); selL = wave_min_dpp(selL);
             u64 rv = 0, lv = 0;
-            if (selR != ~0ull) { const u32 en = (u32)selR; const int j = (int)(selR >> 48), L2 = 0xFFFF - (int)((selR >> 32) & 0xFFFF);
-                rv = (u64)(en >> 2) | ((u64)((en & 3) == 2 ? 1 : 0) << 40) | ((u64)((u32)(L2 - (L1 - j)) & 0x3FFFFFu) << 42); }
-            if (selL != ~0ull) { const u32 en = (u32)selL; const int j = 0x3FFF - (int)(selL >> 48), L2 = 0xFFFF - (int)((selL >> 32) & 0xFFFF);
-                lv = (u64)(en >> 2) | ((u64)((en & 3) == 3 ? 1 : 0) << 40) | ((u64)((u32)(L2 - j - h) & 0x3FFFFFu) << 42); }
-            A.right[i] = rv; A.left[i] = lv; A.conn[i] = nh;
+            if (selR != ~0u) {
+                const int ol = (int)(selR & 63u); const bool oq = ((selR >> 6) & 1u) != 0;
+                const u32 en = (u32)__builtin_amdgcn_readlane((int)(oq ? myEnt[1] : myEnt[0]), ol);
+                const int j = __builtin_amdgcn_readlane(oq ? myJ[1] : myJ[0], ol), L2 = __builtin_amdgcn_readlane(oq ? myL2[1] : myL2[0], ol);
+                rv = (u64)(en >> 2) | ((u64)((en & 3) == 2 ? 1 : 0) << 40) | ((u64)((u32)(L2 - (L1 - j)) & 0x3FFFFFu) << 42);
+            }
+            if (selL != ~0u) {
+                const int ol = (int)(selL & 63u); const bool oq = ((selL >> 6) & 1u) != 0;
+                const u32 en = (u32)__builtin_amdgcn_readlane((int)(oq ? myEnt[1] : myEnt[0]), ol);
+                const int j = __builtin_amdgcn_readlane(oq ? myJ[1] : myJ[0], ol), L2 = __builtin_amdgcn_readlane(oq ? myL2[1] : myL2[0], ol);
+                lv = (u64)(en >> 2) | ((u64)((en & 3) == 3 ? 1 : 0) << 40) | ((u64)((u32)(L2 - j - h) & 0x3FFFFFu) << 42);
+            }
+            if (lane == 0) { A.right[i] = rv; A.left[i] = lv; A.conn[i] = nhits; }
         }
     }
 }
@@ -1036,7 +1106,7 @@ int dev_lookup(Device* d, uint64_t hi, uint64_t lo, uint64_t* entries, uint32_t 
     if (!d->slots) { err = "index not built"; return SAGE2OV_ERR_ARG; }
     u64* out = nullptr; const u32 c2 = std::min<u32>(cap, 128);
     HIPCHK(hipMalloc(&out, (129) * sizeof(u64)));
-    hipLaunchKernelGGL(k_lookup, dim3(1), dim3(1), 0, d->stream, d->slots, d->T, d->csr, d->seed, (u64)hi, (u64)lo, out, c2);
+    hipLaunchKernelGGL(k_lookup, dim3(1), dim3(1), 0, d->stream, d->slots, d->T, d->csr, d->seed, d->h, (u64)hi, (u64)lo, out, c2);
     u64 host[129];
     HIPCHK(hipMemcpyAsync(host, out, sizeof host, hipMemcpyDeviceToHost, d->stream));
     HIPCHK(hipStreamSynchronize(d->stream));
@@ -1069,8 +1139,8 @@ static ProbeArgs base_args(Device* d) {
     return A;
 }
 
-template <int S, int W, int WPB>
-static void launch_fast(Device* d, ProbeArgs& A, unsigned blocks) { hipLaunchKernelGGL((k_probe_fast<S, W, WPB>), dim3(blocks), dim3(64 * WPB), 0, d->stream, A); }
+template <int S, int NW, int WPL, int WPB>
+static void launch_fast(Device* d, ProbeArgs& A, unsigned blocks) { hipLaunchKernelGGL((k_probe_fast<S, NW, WPL, WPB>), dim3(blocks), dim3(64 * WPB), 0, d->stream, A); }
 
 int dev_probe(Device* d, uint64_t lo, uint64_t hi, std::string& err) {
     HIPCHK(hipSetDevice(d->ordinal));
@@ -1087,18 +1157,22 @@ int dev_probe(Device* d, uint64_t lo, uint64_t hi, std::string& err) {
     if (nreads && !seq_only) {
         HIPCHK(hipMalloc(&slow, nreads * sizeof(u32)));
         A.slow = slow; A.slow_cap = nreads;
-        const int Wn = (d->maxL + 31) / 32;                                  // words that carry bases
+        const int nwinMax = d->maxL - d->h + 1;                               // windows of the longest read
         const unsigned wpb = 4;
         const unsigned blocks = (unsigned)std::min<u64>((nreads + wpb - 1) / wpb, 256ull * 64);
         HIPCHK(hipEventRecord(d->ev[2], d->stream));
-        if (d->S == 4) launch_fast<4, 4, 4>(d, A, blocks);
-        else if (d->S == 8 && Wn <= 5) launch_fast<8, 5, 4>(d, A, blocks);
-        else if (d->S == 8) launch_fast<8, 8, 4>(d, A, blocks);
-        else launch_fast<16, 16, 2>(d, A, (unsigned)std::min<u64>((nreads + 1) / 2, 256ull * 64));
+        bool launched = true;
+        if (d->S == 4 && nwinMax <= 128) launch_fast<4, 8, 2, 4>(d, A, blocks);
+        else if (d->S == 8 && d->maxL <= 160 && nwinMax <= 128) launch_fast<8, 10, 2, 4>(d, A, blocks);
+        else if (d->S == 8 && d->maxL <= 160) launch_fast<8, 10, 4, 4>(d, A, blocks);
+        else if (d->S == 8 && nwinMax <= 128) launch_fast<8, 16, 2, 4>(d, A, blocks);
+        else if (d->S == 8) launch_fast<8, 16, 4, 4>(d, A, blocks);
+        else launched = false;                                                // 16-word layout: sequential kernel only (for now)
+        if (!launched) { hipFree(slow); slow = nullptr; int rc = launch_probe<0>(d, A, err); if (rc) return rc; }
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(d->ev[3], d->stream));
         u64 nslow = 0;
-        HIPCHK(hipMemcpyAsync(&nslow, d->d_counters + 6, sizeof nslow, hipMemcpyDeviceToHost, d->stream));
+        if (launched) HIPCHK(hipMemcpyAsync(&nslow, d->d_counters + 6, sizeof nslow, hipMemcpyDeviceToHost, d->stream));
         HIPCHK(hipStreamSynchronize(d->stream));
         float ms = 0; hipEventElapsedTime(&ms, d->ev[2], d->ev[3]); d->tm.probe_kernel_ms += ms; d->tm.probe_launches++;
         d->tm.slow_reads += nslow;
