@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsage2ov.so")
+LIB_PATH = os.environ.get("SAGE2OV_LIB") or os.path.join(_HERE, "libsage2ov.so")     # override only for A/B builds
 
 
 class Sage2ovError(RuntimeError):

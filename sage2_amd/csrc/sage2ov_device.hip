@@ -47,7 +47,26 @@ struct Device {
     FinalEdge* final_edges = nullptr; u64 n_final = 0;
     DevTimings tm;
     std::vector<u32> dbg_where; std::vector<u64> dbg_keys;
+    // workspace arena: buffers of the timed path are allocated once and only ever grow (no hipMalloc/hipFree per step)
+    struct Buf { void* p = nullptr; size_t cap = 0; };
+    Buf ws[32];
 };
+enum { WS_SLOTS, WS_CNT, WS_WHERE, WS_BIG, WS_CSR, WS_SLOW, WS_NEED, WS_DEG, WS_OFFS, WS_CURSOR, WS_KEYS, WS_KEEP, WS_POS, WS_OWNER, WS_FINAL,
+       WS_PARTIAL, WS_IDS, WS_NEAR, WS_HITS };
+static void* ws_get(Device* d, int id, size_t bytes) {
+    Device::Buf& b = d->ws[id];
+    if (b.cap < bytes || !b.p) {
+        if (b.p) hipFree(b.p);
+        b.p = nullptr; b.cap = 0;
+        size_t want = bytes + bytes / 16 + 256;
+        if (hipMalloc(&b.p, want) != hipSuccess) { b.p = nullptr; return nullptr; }
+        b.cap = want;
+    }
+    return b.p;
+}
+#define WS(var, type, id, count)                                                                     \
+    type* var = (type*)ws_get(d, id, (size_t)(count) * sizeof(type));                                \
+    if (!var) { err = std::string("workspace allocation failed: ") + #id; return SAGE2OV_ERR_NOMEM; }
 
 // =============================================================================================
 // device helpers
@@ -631,8 +650,11 @@ __device__ __forceinline__ int first_mismatch(const u32 (&Y)[NW], const u32* E, 
     return fm;
 }
 
+#ifndef SAGE2OV_FAST_WAVES
+#define SAGE2OV_FAST_WAVES 5
+#endif
 template <int S, int NW, int WPL, int WPB>
-__global__ __launch_bounds__(64 * WPB) void k_probe_fast(ProbeArgs A) {
+__global__ __launch_bounds__(64 * WPB, SAGE2OV_FAST_WAVES) void k_probe_fast(ProbeArgs A) {
     __shared__ FastLds<S> lds_all[WPB];
     FastLds<S>& L = lds_all[threadIdx.x >> 6];
     const u32 lane = lane_id();
@@ -726,10 +748,17 @@ __global__ __launch_bounds__(64 * WPB) void k_probe_fast(ProbeArgs A) {
             }
 #pragma unroll
             for (int q = 0; q < 2; q++) {
-                const u64* yp = A.reads + (gate[q] ? (u64)(myEnt[q] >> 2) : 0ull) * S;       // gated-off lanes read slot 0 (zeros)
+                // 16-byte loads of the (at least 32-byte aligned) slot; gated-off lanes read slot 0 (zeros, always cached)
+                const uint4* yp = (const uint4*)(A.reads + (gate[q] ? (u64)(myEnt[q] >> 2) : 0ull) * S);
 #pragma unroll
-                for (int c = 0; c < NW / 2; c++) { const u64 w = yp[c]; Y[q][2 * c] = (u32)(w >> 32); Y[q][2 * c + 1] = (u32)w; }
-                myL2[q] = (int)(yp[S - 1] & 0xFFFF);
+                for (int c = 0; c < (NW + 3) / 4; c++) {
+                    const uint4 v = yp[c];                       // memory dwords 4c..4c+3 = (lo,hi) of words 2c, 2c+1
+                    if (4 * c + 0 < NW) Y[q][4 * c + 0] = v.y;
+                    if (4 * c + 1 < NW) Y[q][4 * c + 1] = v.x;
+                    if (4 * c + 2 < NW) Y[q][4 * c + 2] = v.w;
+                    if (4 * c + 3 < NW) Y[q][4 * c + 3] = v.z;
+                }
+                myL2[q] = (int)(((const u32*)yp)[2 * S - 2] & 0xFFFFu);     // low dword of the last word
                 if (NW == D) Y[q][NW - 1] &= 0xFFFF0000u;
             }
             // ---------------------------------------------------------------- 3. speculation: furthest reach per side
@@ -1013,8 +1042,9 @@ Device* dev_create(int ordinal, std::string& err) {
     return d;
 }
 static void free_reads(Device* d) {
-    hipFree(d->reads); hipFree(d->slots); hipFree(d->csr); hipFree(d->right); hipFree(d->left); hipFree(d->conn); hipFree(d->cflag);
-    hipFree(d->status); hipFree(d->cand); hipFree(d->final_edges);
+    hipFree(d->reads); hipFree(d->right); hipFree(d->left); hipFree(d->conn); hipFree(d->cflag);
+    hipFree(d->status); hipFree(d->cand);     // slots / csr / final_edges live in the workspace arena
+    for (auto& b : d->ws) { if (b.p) hipFree(b.p); b.p = nullptr; b.cap = 0; }
     d->reads = d->slots = nullptr; d->csr = nullptr; d->right = d->left = nullptr; d->conn = d->cflag = nullptr; d->status = nullptr; d->cand = nullptr; d->final_edges = nullptr;
 }
 void dev_destroy(Device* d) {
@@ -1051,14 +1081,14 @@ int dev_upload_reads(Device* d, const uint64_t* words, uint64_t N, int S, int ma
 int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t* csr_out, uint64_t* nlong_out, uint32_t* rebuilds, std::string& err) {
     HIPCHK(hipSetDevice(d->ordinal));
     const u64 N = d->N; if (!d->reads) { err = "reads not resident"; return SAGE2OV_ERR_ARG; }
-    hipFree(d->slots); hipFree(d->csr); d->slots = nullptr; d->csr = nullptr;
     d->T = std::max<u64>(1024, 8 * N);                                   // load <= 0.5, as hashTable.cpp:83 sizes it
     if (d->T >= (1ull << 32)) { err = "table too large for 32-bit slot indices"; return SAGE2OV_ERR_LIMIT; }
-    HIPCHK(hipMalloc(&d->slots, d->T * sizeof(u64)));
-    u32 *cnt = nullptr, *where = nullptr; u64* big = nullptr; const u32 big_cap = 1u << 20;
-    HIPCHK(hipMalloc(&cnt, d->T * sizeof(u32))); HIPCHK(hipMalloc(&where, std::max<u64>(1, 4 * N) * sizeof(u32)));
-    HIPCHK(hipMalloc(&big, (u64)big_cap * 3 * sizeof(u64)));
-    HIPCHK(hipMalloc(&d->csr, std::max<u64>(1, 4 * N) * sizeof(u32)));
+    const u32 big_cap = 1u << 20;
+    WS(slots_ws, u64, WS_SLOTS, d->T); d->slots = slots_ws;
+    WS(cnt, u32, WS_CNT, d->T);
+    WS(where, u32, WS_WHERE, std::max<u64>(1, 4 * N));
+    WS(big, u64, WS_BIG, (u64)big_cap * 3);
+    WS(csr_ws, u32, WS_CSR, std::max<u64>(1, 4 * N)); d->csr = csr_ws;
     HIPCHK(hipEventRecord(d->ev[0], d->stream));
     *rebuilds = 0;
     for (int attempt = 0;; attempt++) {
@@ -1082,21 +1112,20 @@ int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t
         u64 c[5];
         HIPCHK(hipMemcpyAsync(c, d->d_counters + 8, sizeof c, hipMemcpyDeviceToHost, d->stream));
         HIPCHK(hipStreamSynchronize(d->stream));
-        if (c[2] > big_cap) { err = "too many long buckets"; hipFree(cnt); hipFree(where); hipFree(big); return SAGE2OV_ERR_LIMIT; }
+        if (c[2] > big_cap) { err = "too many long buckets"; return SAGE2OV_ERR_LIMIT; }
         if (c[2]) {
             hipLaunchKernelGGL(k_index_purity, dim3(grid_for(c[2] * 64, 256)), dim3(256), 0, d->stream, d->reads, d->S, d->h, big, c[2], d->csr, d->d_counters + 8);
             HIPCHK(hipMemcpyAsync(c, d->d_counters + 8, sizeof c, hipMemcpyDeviceToHost, d->stream));
             HIPCHK(hipStreamSynchronize(d->stream));
         }
         if (c[3] == 0) { d->n_csr = c[0]; d->n_keys = c[1]; d->n_long = c[2]; break; }
-        if (attempt >= 8) { err = "index build: tag collisions in long buckets persist after 8 reseeds"; hipFree(cnt); hipFree(where); hipFree(big); return SAGE2OV_ERR_INTERNAL; }
+        if (attempt >= 8) { err = "index build: tag collisions in long buckets persist after 8 reseeds"; return SAGE2OV_ERR_INTERNAL; }
         d->seed = d->seed * 0x9E3779B97F4A7C15ull + 12345; (*rebuilds)++;
     }
     HIPCHK(hipEventRecord(d->ev[1], d->stream));
     HIPCHK(hipStreamSynchronize(d->stream));
     float ms = 0; hipEventElapsedTime(&ms, d->ev[0], d->ev[1]); d->tm.index_ms += ms;
     if (getenv("SAGE2OV_DBG_WHERE")) { d->dbg_where.resize(4 * N); HIPCHK(hipMemcpy(d->dbg_where.data(), where, 4 * N * sizeof(u32), hipMemcpyDeviceToHost)); }
-    hipFree(cnt); hipFree(where); hipFree(big);
     *slots_out = d->T; *keys_out = d->n_keys; *csr_out = d->n_csr; *nlong_out = d->n_long;
     return 0;
 }
@@ -1153,9 +1182,8 @@ int dev_probe(Device* d, uint64_t lo, uint64_t hi, std::string& err) {
     ProbeArgs A = base_args(d); A.lo = lo; A.hi = hi;
     const u64 nreads = hi > lo ? hi - lo : 0;
     const bool seq_only = getenv("SAGE2OV_SEQUENTIAL_PROBE") != nullptr;
-    u32* slow = nullptr;
     if (nreads && !seq_only) {
-        HIPCHK(hipMalloc(&slow, nreads * sizeof(u32)));
+        WS(slow, u32, WS_SLOW, nreads);
         A.slow = slow; A.slow_cap = nreads;
         const int nwinMax = d->maxL - d->h + 1;                               // windows of the longest read
         const unsigned wpb = 4;
@@ -1168,7 +1196,7 @@ int dev_probe(Device* d, uint64_t lo, uint64_t hi, std::string& err) {
         else if (d->S == 8 && nwinMax <= 128) launch_fast<8, 16, 2, 4>(d, A, blocks);
         else if (d->S == 8) launch_fast<8, 16, 4, 4>(d, A, blocks);
         else launched = false;                                                // 16-word layout: sequential kernel only (for now)
-        if (!launched) { hipFree(slow); slow = nullptr; int rc = launch_probe<0>(d, A, err); if (rc) return rc; }
+        if (!launched) { int rc = launch_probe<0>(d, A, err); if (rc) return rc; }
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(d->ev[3], d->stream));
         u64 nslow = 0;
@@ -1178,7 +1206,7 @@ int dev_probe(Device* d, uint64_t lo, uint64_t hi, std::string& err) {
         d->tm.slow_reads += nslow;
         if (nslow) {                                                          // ambiguous / overflowing reads: sequential state machine
             ProbeArgs B = base_args(d); B.ids = slow; B.n_ids = nslow;
-            int rc = launch_probe<0>(d, B, err); if (rc) { hipFree(slow); return rc; }
+            int rc = launch_probe<0>(d, B, err); if (rc) return rc;
         }
     } else if (nreads) {
         HIPCHK(hipEventRecord(d->ev[2], d->stream));
@@ -1189,7 +1217,6 @@ int dev_probe(Device* d, uint64_t lo, uint64_t hi, std::string& err) {
     }
     HIPCHK(hipEventRecord(d->ev[1], d->stream));
     HIPCHK(hipStreamSynchronize(d->stream));
-    if (slow) hipFree(slow);
     float ms = 0; hipEventElapsedTime(&ms, d->ev[0], d->ev[1]); d->tm.probe_ms += ms;
     return 0;
 }
@@ -1295,23 +1322,21 @@ int dev_unresolved_hits(Device* d, std::vector<Hit>& hits, uint64_t* n_unresolve
     if (nun == 0) return 0;
     u64 cap = std::max<u64>(1 << 16, nun * 80);
     for (int attempt = 0; attempt < 4; attempt++) {
-        Hit* dh = nullptr;
-        HIPCHK(hipMalloc(&dh, cap * sizeof(Hit)));
+        WS(dh, Hit, WS_HITS, cap);
         HIPCHK(hipMemsetAsync(d->d_counters + 4, 0, sizeof(u64), d->stream));
         ProbeArgs A = base_args(d); A.lo = 1; A.hi = N + 1; A.hits = dh; A.hits_cap = cap;
-        rc = launch_probe<1>(d, A, err); if (rc) { hipFree(dh); return rc; }
+        rc = launch_probe<1>(d, A, err); if (rc) return rc;
         u64 nh = 0;
         HIPCHK(hipMemcpyAsync(&nh, d->d_counters + 4, sizeof nh, hipMemcpyDeviceToHost, d->stream));
         HIPCHK(hipStreamSynchronize(d->stream));
         if (nh <= cap) {
             hits.resize(nh);
             if (nh) HIPCHK(hipMemcpy(hits.data(), dh, nh * sizeof(Hit), hipMemcpyDeviceToHost));
-            hipFree(dh);
             HIPCHK(hipEventRecord(d->ev[1], d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
             float ms = 0; hipEventElapsedTime(&ms, d->ev[0], d->ev[1]); d->tm.hits_ms += ms;
             return 0;
         }
-        hipFree(dh); cap = nh + 1024;
+        cap = nh + 1024;
     }
     err = "hit buffer sizing failed"; return SAGE2OV_ERR_INTERNAL;
 }
@@ -1322,35 +1347,33 @@ int dev_unresolved_hits(Device* d, std::vector<Hit>& hits, uint64_t* n_unresolve
 int dev_collect_reduce_edges(Device* d, std::vector<EdgeCand>& out, std::string& err) {
     HIPCHK(hipSetDevice(d->ordinal));
     out.clear(); const u64 n = d->n_cand; if (n == 0) return 0;
-    uint8_t* need = nullptr; EdgeCand* buf = nullptr; u64 cap = 1 << 16;
-    HIPCHK(hipMalloc(&need, d->N + 1)); HIPCHK(hipMemsetAsync(need, 0, d->N + 1, d->stream));
+    EdgeCand* buf = nullptr; u64 cap = 1 << 16;
+    WS(need, uint8_t, WS_NEED, d->N + 1); HIPCHK(hipMemsetAsync(need, 0, d->N + 1, d->stream));
     hipLaunchKernelGGL(k_red_mark, dim3(grid_for(n, 256)), dim3(256), 0, d->stream, d->cand, (u64)n, d->status, need);
     // first a dry count (cap 0 keeps the flagging idempotent), then the real collection
     HIPCHK(hipMemsetAsync(d->d_counters + 5, 0, sizeof(u64), d->stream));
     hipLaunchKernelGGL(k_red_collect, dim3(grid_for(n, 256)), dim3(256), 0, d->stream, d->cand, (u64)n, d->status, need, (EdgeCand*)nullptr, (u64)0, d->d_counters + 5);
     u64 cnt = 0; HIPCHK(hipMemcpyAsync(&cnt, d->d_counters + 5, sizeof cnt, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
     if (cnt) {
-        cap = cnt; HIPCHK(hipMalloc(&buf, cap * sizeof(EdgeCand)));
+        cap = cnt; { WS(nb_, EdgeCand, WS_NEAR, cap); buf = nb_; }
         HIPCHK(hipMemsetAsync(d->d_counters + 5, 0, sizeof(u64), d->stream));
         hipLaunchKernelGGL(k_red_collect, dim3(grid_for(n, 256)), dim3(256), 0, d->stream, d->cand, (u64)n, d->status, need, buf, cap, d->d_counters + 5);
         HIPCHK(hipStreamSynchronize(d->stream));
         out.resize(cnt); HIPCHK(hipMemcpy(out.data(), buf, cnt * sizeof(EdgeCand), hipMemcpyDeviceToHost));
         for (auto& e : out) e.type &= 0x7Fu;
-        hipFree(buf);
     }
-    hipFree(need);
     return 0;
 }
 int dev_unresolved_ids(Device* d, std::vector<uint32_t>& ids, std::string& err) {
     HIPCHK(hipSetDevice(d->ordinal));
     ids.clear(); u64 cap = 1 << 20; 
     for (int attempt = 0; attempt < 2; attempt++) {
-        u32* buf = nullptr; HIPCHK(hipMalloc(&buf, cap * sizeof(u32)));
+        WS(buf, u32, WS_IDS, cap);
         HIPCHK(hipMemsetAsync(d->d_counters + 5, 0, sizeof(u64), d->stream));
         hipLaunchKernelGGL(k_red_unresolved, dim3(grid_for(d->N, 256)), dim3(256), 0, d->stream, (u64)d->N, d->status, buf, cap, d->d_counters + 5);
         u64 cnt = 0; HIPCHK(hipMemcpyAsync(&cnt, d->d_counters + 5, sizeof cnt, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
-        if (cnt <= cap) { ids.resize(cnt); if (cnt) HIPCHK(hipMemcpy(ids.data(), buf, cnt * sizeof(u32), hipMemcpyDeviceToHost)); hipFree(buf); std::sort(ids.begin(), ids.end()); return 0; }
-        hipFree(buf); cap = cnt;
+        if (cnt <= cap) { ids.resize(cnt); if (cnt) HIPCHK(hipMemcpy(ids.data(), buf, cnt * sizeof(u32), hipMemcpyDeviceToHost)); std::sort(ids.begin(), ids.end()); return 0; }
+        cap = cnt;
     }
     err = "unresolved id collection failed"; return SAGE2OV_ERR_INTERNAL;
 }
@@ -1408,14 +1431,12 @@ int dev_append_edges(Device* d, const EdgeCand* e, uint64_t n, std::string& err)
 
 static int scan_u32(Device* d, const u32* in, u64 n, u32* out, u64* total, std::string& err) {
     const u64 nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
-    u64* partial = nullptr;
-    HIPCHK(hipMalloc(&partial, (nb + 1) * sizeof(u64)));
+    WS(partial, u64, WS_PARTIAL, nb + 1);
     hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, d->stream, in, (u64)n, partial);
     hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, d->stream, partial, (u64)nb, partial + nb);
     hipLaunchKernelGGL(k_scan_final, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, d->stream, in, (u64)n, partial, out);
     HIPCHK(hipMemcpyAsync(total, partial + nb, sizeof(u64), hipMemcpyDeviceToHost, d->stream));
     HIPCHK(hipStreamSynchronize(d->stream));
-    hipFree(partial);
     return 0;
 }
 
@@ -1428,13 +1449,12 @@ int dev_download_edges(Device* d, std::vector<FinalEdge>& out, std::string& err)
 int dev_convert(Device* d, uint64_t* n_final, std::string& err) {
     HIPCHK(hipSetDevice(d->ordinal));
     const u64 N = d->N, n = d->n_cand;
-    hipFree(d->final_edges); d->final_edges = nullptr; d->n_final = 0;
+    d->final_edges = nullptr; d->n_final = 0;
     HIPCHK(hipEventRecord(d->ev[0], d->stream));
     if (n) {
         if (n >= (1ull << 32)) { err = "too many edge candidates"; return SAGE2OV_ERR_LIMIT; }
-        u32 *deg = nullptr, *offs = nullptr, *cursor = nullptr, *keep = nullptr, *pos = nullptr, *owner = nullptr; u64* keys = nullptr;
-        HIPCHK(hipMalloc(&deg, (N + 2) * sizeof(u32))); HIPCHK(hipMalloc(&offs, (N + 2) * sizeof(u32))); HIPCHK(hipMalloc(&cursor, (N + 2) * sizeof(u32)));
-        HIPCHK(hipMalloc(&keys, n * sizeof(u64))); HIPCHK(hipMalloc(&keep, n * sizeof(u32))); HIPCHK(hipMalloc(&pos, n * sizeof(u32))); HIPCHK(hipMalloc(&owner, n * sizeof(u32)));
+        WS(deg, u32, WS_DEG, N + 2); WS(offs, u32, WS_OFFS, N + 2); WS(cursor, u32, WS_CURSOR, N + 2);
+        WS(keys, u64, WS_KEYS, n); WS(keep, u32, WS_KEEP, n); WS(pos, u32, WS_POS, n); WS(owner, u32, WS_OWNER, n);
         HIPCHK(hipMemsetAsync(deg, 0, (N + 2) * sizeof(u32), d->stream)); HIPCHK(hipMemsetAsync(cursor, 0, (N + 2) * sizeof(u32), d->stream));
         hipLaunchKernelGGL(k_conv_degree, dim3(grid_for(n, 256)), dim3(256), 0, d->stream, d->cand, (u64)n, deg);
         u64 tot = 0; int rc = scan_u32(d, deg, N + 1, offs, &tot, err); if (rc) return rc;
@@ -1445,12 +1465,11 @@ int dev_convert(Device* d, uint64_t* n_final, std::string& err) {
         u64 nf = 0;
         if (tot) {
             rc = scan_u32(d, keep, tot, pos, &nf, err); if (rc) return rc;
-            HIPCHK(hipMalloc(&d->final_edges, std::max<u64>(1, nf) * sizeof(FinalEdge)));
+            { WS(fe, FinalEdge, WS_FINAL, std::max<u64>(1, nf)); d->final_edges = fe; }
             hipLaunchKernelGGL(k_conv_emit, dim3(grid_for(tot, 256)), dim3(256), 0, d->stream, (u64)tot, keys, keep, pos, owner, d->reads, d->S, d->final_edges);
         }
         d->n_final = nf;
         HIPCHK(hipStreamSynchronize(d->stream));
-        hipFree(deg); hipFree(offs); hipFree(cursor); hipFree(keys); hipFree(keep); hipFree(pos); hipFree(owner);
     }
     HIPCHK(hipEventRecord(d->ev[1], d->stream));
     HIPCHK(hipStreamSynchronize(d->stream));
