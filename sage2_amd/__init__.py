@@ -56,12 +56,30 @@ EDGE_DTYPE = np.dtype([("from", "<u8"), ("to", "<u8"), ("length", "<u4"), ("leng
 _lib = None
 
 
+def _preload_torch_hip():
+    """libsage2ov.so and PyTorch-ROCm both need `libamdhip64.so.7`; torch ships its own copy next to its other
+    ROCm libraries.  Whichever copy is mapped first serves both, and torch only finds its GPUs with ITS copy, so
+    when torch is installed map that one first (no torch import needed).  The C++ CLI uses /opt/rocm's."""
+    if os.environ.get("SAGE2OV_NO_TORCH_HIP"):
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec and spec.origin:
+            cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+            if os.path.exists(cand):
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
 def lib():
     """Load libsage2ov.so (fails loudly when it has not been built)."""
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C sage2_amd/csrc`")
+        _preload_torch_hip()
         L = C.CDLL(LIB_PATH)
         L.sage2ov_last_error.restype = C.c_char_p
         L.sage2ov_last_error.argtypes = [C.c_void_p]

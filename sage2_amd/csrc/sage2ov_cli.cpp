@@ -1,0 +1,127 @@
+// sage2_amd/csrc/sage2ov_cli.cpp -- `sage2ov`: drop-in producer of <outdir>/<prefix>.reads and <prefix>.graph3.
+// Mimics the SAGE2 command line for steps 1-3 (main.cpp:384-521): -f | -l, -k, -o, -p, -i, -m, -M, -s, -d, -h.
+// Continue with the unchanged reference:  SAGE2 -f reads.fa -k K -o out -p P -i P -m 4      (main.cpp:141-148)
+#include <getopt.h>
+#include <sys/stat.h>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <string>
+#include "sage2ov.hpp"
+
+using namespace std;
+using namespace sage2ov;
+
+static void printUsage() {
+    cout << "USAGE:\n\tsage2ov [options] -f <inputFile> -k <minOverlap>   (steps 1-3 of SAGE2 on an MI355X)\n"
+            "\tsage2ov [options] -l <listInput> -k <minOverlap>\n\n";
+}
+static void printListOfArgs() {
+    cout << "\t-f|--fileInput <string>\tinterleaved FASTA/FASTQ(.gz)\n\t-l|--listInput <string>\tlist file (f1=/f2=/f=)\n"
+            "\t-k|--minOverlap <int>\tminimum overlap (required)\n\t-o|--outputDir <string>\n\t-p|--prefix <string>\t[untitled]\n"
+            "\t-i|--inputPrefix <string>\t[prefix]\n\t-m|--minStep <int>\t[1]\n\t-M|--maxStep <int>\t[3] (steps 4-7: run SAGE2 -m 4 on the files written here)\n"
+            "\t-s|--saveAll\n\t-d|--debug\n\t-g|--gpu <int>\tHIP device ordinal [0]\n\t-h|--help\n\n";
+}
+static string trimBack(string s, const string& pat) { size_t e = s.find_last_not_of(pat); return e == string::npos ? "" : s.substr(0, e + 1); }
+static double now() { return chrono::duration<double>(chrono::steady_clock::now().time_since_epoch()).count(); }
+
+int main(int argc, char* argv[]) {
+    int minStep = 1, maxStep = 3, gpu = 0; unsigned minOverlap = 0; bool saveAll = false, debugging = false, fFlag = false, lFlag = false;
+    string fileInput, listInput, outputDir, prefixName = "untitled", inputPrefix;
+    static struct option opts[] = {{"help", no_argument, 0, 'h'}, {"fileInput", required_argument, 0, 'f'}, {"minOverlap", required_argument, 0, 'k'},
+        {"listInput", required_argument, 0, 'l'}, {"outputDir", required_argument, 0, 'o'}, {"prefix", required_argument, 0, 'p'},
+        {"inputPrefix", required_argument, 0, 'i'}, {"minStep", required_argument, 0, 'm'}, {"maxStep", required_argument, 0, 'M'},
+        {"saveAll", no_argument, 0, 's'}, {"debug", no_argument, 0, 'd'}, {"gpu", required_argument, 0, 'g'}, {0, 0, 0, 0}};
+    int c, oi = 0;
+    while ((c = getopt_long(argc, argv, "hf:l:k:o:p:i:m:M:sdg:", opts, &oi)) != -1) {
+        switch (c) {
+            case 'h': cout << "\n"; printUsage(); printListOfArgs(); exit(0);
+            case 'f': fileInput = optarg; fFlag = true; break;
+            case 'l': listInput = optarg; lFlag = true; break;
+            case 'k': minOverlap = atoi(optarg); break;
+            case 'o': outputDir = optarg; if (outputDir != "") outputDir = trimBack(outputDir, "/") + "/"; break;   // main.cpp:438-442
+            case 'p': prefixName = optarg; break;
+            case 'i': inputPrefix = optarg; break;
+            case 'm': minStep = atoi(optarg); if (minStep < 1) minStep = 1; break;
+            case 'M': maxStep = atoi(optarg); if (maxStep > 7) maxStep = 7; break;
+            case 's': saveAll = true; break;
+            case 'd': debugging = true; break;
+            case 'g': gpu = atoi(optarg); break;
+            case '?': cout << "\n"; exit(0);
+            default: cout << "[ERROR] Wrong command line arguments!\n\n"; exit(0);
+        }
+    }
+    if (fFlag && lFlag) { cout << "[ERROR] Options -f|--fileInput and -l|--listInput are mutually exclusive!\n\n"; exit(0); }
+    bool allSet = true;                                                                     // main.cpp:498-521
+    if (fileInput == "" && listInput == "" && minStep <= 1) { cout << "[ERROR] One of the options -f|--fileInput or -l|--listInput is required.\n"; allSet = false; }
+    if (minOverlap == 0) { cout << "[ERROR] Option -k|--minOverlap is required.\n"; allSet = false; }
+    if (maxStep < minStep) { cout << "[ERROR] maxStep should not be smaller than minStep!\n\n"; allSet = false; }
+    if (inputPrefix == "") inputPrefix = prefixName;
+    if (!allSet) { cout << "\n"; printUsage(); cout << "(For more information run sage2ov -h)\n\n"; exit(0); }
+    if (minStep > 3) { cout << "[ERROR] sage2ov implements steps 1-3; continue with: SAGE2 -m " << minStep << " -i " << inputPrefix << " ...\n"; exit(0); }
+    (void)debugging;
+    if (outputDir != "") { string cmd = "mkdir -p " + outputDir; if (system(cmd.c_str())) {} }     // utils.cpp:45
+    ofstream logStream((outputDir + prefixName + ".log").c_str());
+    logStream << "***********************************************************************************************************\n"
+              << "\tEXECUTING PROGRAM: sage2ov (MI355X-native SAGE2 steps 1-3), " << sage2ov_version() << "\n"
+              << (listInput != "" ? "\t  INPUT LIST PATH: " + listInput : "\t  INPUT FILE PATH: " + fileInput) << "\n"
+              << "\t OUTPUT DIRECTORY: " << outputDir << "\n\t    OUTPUT PREFIX: " << prefixName << "\n\t  MINIMUM OVERLAP: " << minOverlap << "\n"
+              << "\t       START STEP: " << minStep << "\n\t         END STEP: " << maxStep << "\n\t   SAVE ALL FILES: " << (saveAll ? "TRUE" : "FALSE") << "\n"
+              << "***********************************************************************************************************\n\n";
+    const int lastStep = maxStep > 3 ? 3 : maxStep;
+    try {
+        Context ctx((uint16_t)minOverlap, lastStep == 1 ? SAGE2OV_DEVICE_NONE : gpu);
+        ReadLoader loaderObj(ctx);
+        double t0 = now();
+        if (minStep <= 1) {                                                                  // main.cpp:37-61
+            logStream << "STEP 1: organizing reads\n";
+            if (listInput != "") loaderObj.loadFromList(listInput); else loaderObj.readDatasetInBytes(fileInput);
+            loaderObj.organizeReads();
+            auto s = loaderObj.stats();
+            logStream << "\tTotal reads: " << s.total_reads << "\n\tGood reads: " << s.good_reads << "\n\tNumber of unique reads: " << s.unique_reads
+                      << "\n\tAverage read length: " << s.average_read_length << "\n\tStep 1 in " << now() - t0 << " sec.\n";
+            if (lastStep == 1 || saveAll) loaderObj.saveReadsInFile(outputDir + prefixName + ".reads");
+        } else {
+            loaderObj.loadReadsFromFile(outputDir + inputPrefix + ".reads");                 // main.cpp:70-74 / :101-104
+            logStream << "\tNumber of unique reads: " << loaderObj.numberOfUniqueReads << " (loaded)\n";
+        }
+        if (lastStep >= 2) {
+            HashTable hashObj(&loaderObj);
+            t0 = now(); hashObj.hashPrefixesAndSuffix();                                      // main.cpp:76-77 (always rebuilt: P.hashTable is not read)
+            auto is = hashObj.stats();
+            logStream << "STEP 2: building hash table\n\t         Hash string length: " << is.hash_string_length << "\n\t            Hash table size: " << is.slots
+                      << "\n\t Number of hash elements over threshold: " << is.long_buckets << "\n\tStep 2 in " << now() - t0 << " sec.\n";
+            if (lastStep == 2) {
+                if (minStep == 1 && !saveAll) loaderObj.saveReadsInFile(outputDir + prefixName + ".reads");
+                logStream << "\t(P.hashTable is not written: SAGE2 -m 4 does not need it and sage2ov -m 3 rebuilds the index)\n";
+            }
+            if (lastStep >= 3) {                                                              // main.cpp:92-132
+                EconomyGraph economyObj(&hashObj);
+                t0 = now(); economyObj.buildInitialOverlapGraph();
+                auto os = economyObj.stats();
+                logStream << "STEP 3: building overlap graph\n     Total contained by extension: " << os.contained_extension << "\n          Total contained by size: " << os.contained_size
+                          << "\n            Total left to explore: " << os.left_to_explore << "\n              Verified overlaps: " << os.verified_overlaps << "\n";
+                economyObj.buildOverlapGraphEconomy();
+                os = economyObj.stats();
+                logStream << "     Total edges inserted: " << os.edges_inserted << "\n  Transitive edge removed: " << os.transitive_removed << "\n";
+                economyObj.sortEconomyGraph();
+                OverlapGraph graphObj(&economyObj, &loaderObj);
+                graphObj.convertGraph();
+                logStream << "     Edges in the graph: " << economyObj.stats().edges << "\n\tStep 3 in " << now() - t0 << " sec.\n";
+                if (minStep == 1 && !saveAll) loaderObj.saveReadsInFile(outputDir + prefixName + ".reads");
+                graphObj.saveOverlapGraphInFile(outputDir + prefixName + ".graph3");
+            }
+        }
+        if (maxStep > 3) {
+            cout << "sage2ov: steps 1-3 done; continue with the reference: SAGE2 " << (listInput != "" ? "-l " + listInput : "-f " + fileInput) << " -k " << minOverlap
+                 << " -o " << (outputDir == "" ? "." : outputDir) << " -p " << prefixName << " -i " << prefixName << " -m 4 -M " << maxStep << "\n";
+        }
+    } catch (const Error& e) {
+        logStream << "sage2ov error " << e.code << " : " << e.what() << "!\n";               // utils.cpp:36-40 printError
+        cerr << "sage2ov error " << e.code << ": " << e.what() << "\n";
+        return EXIT_FAILURE;
+    }
+    return 0;
+}

@@ -84,3 +84,34 @@ def test_filters_and_errors():
     ctx.close()
     with pytest.raises(s2.Sage2ovError):
         s2.Context(0, device=-2)           # -k is required (main.cpp:506-510)
+
+
+def test_cli_step1_and_reference_tail(tmp_path):
+    """`sage2ov -M 1` (no GPU needed) writes the reference's P.reads; with the P.graph3 our GPU path is proven to
+    reproduce byte for byte (tests/golden), the UNCHANGED reference continues from step 4 to contigs/scaffolds and
+    gives the same result as a reference-only run.  The tail part needs oracle/_ref."""
+    import shutil
+    import subprocess
+    cli = os.path.join(fx.ROOT, "sage2_amd", "sage2ov")
+    if not os.path.exists(cli):
+        pytest.skip("CLI not built")
+    m = fx.golden("g2_clean150_k40")
+    fa = str(tmp_path / "x.fa")
+    s2.synth_write_fasta(fx.synth_params(m["synth"]), fa)
+    out = str(tmp_path / "ours")
+    subprocess.run([cli, "-f", fa, "-k", str(m["k"]), "-o", out, "-p", "t", "-M", "1"], check=True)
+    assert fx.md5_file(os.path.join(out, "t.reads")) == m["reads_md5"]
+    # usage errors print to stdout and exit 0, like the reference (main.cpp:17-24)
+    r = subprocess.run([cli, "-f", fa], stdout=subprocess.PIPE)
+    assert r.returncode == 0 and b"minOverlap is required" in r.stdout
+    ref = os.path.join(fx.ROOT, "oracle", "_ref", "SAGE2")
+    if not os.path.exists(ref):
+        pytest.skip("reference binary not built (only available in the build container)")
+    open(os.path.join(out, "t.graph3"), "wb").write(fx.golden_graph3("g2_clean150_k40"))
+    env = dict(os.environ, OMP_NUM_THREADS="4", LC_ALL="C")
+    subprocess.run([ref, "-f", fa, "-k", str(m["k"]), "-o", out, "-p", "t2", "-i", "t", "-m", "4", "-M", "7"], check=True, env=env, stdout=subprocess.DEVNULL, cwd=str(tmp_path))
+    full = str(tmp_path / "full")
+    subprocess.run([ref, "-f", fa, "-k", str(m["k"]), "-o", full, "-p", "t2", "-M", "7"], check=True, env=env, stdout=subprocess.DEVNULL, cwd=str(tmp_path))
+    for suffix in ("_contig.fasta", "_scaffold.fasta"):
+        a, b = os.path.join(out, "t2" + suffix), os.path.join(full, "t2" + suffix)
+        assert os.path.exists(a) and os.path.exists(b) and open(a, "rb").read() == open(b, "rb").read()

@@ -151,3 +151,106 @@ def test_scale_100k_matches_oracle_and_is_deterministic(pd, k):
         prev = cur
         g.close()
     o.close()
+
+
+class _Hip:
+    """bare hipMalloc/hipMemcpy through ctypes (the runtime libsage2ov.so already mapped): device buffers for the
+    exchange test without bringing a second framework into the test process"""
+    def __init__(self):
+        import ctypes as C
+        self.C = C
+        self.rt = C.CDLL("libamdhip64.so.7")
+        self.rt.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        self.rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self.rt.hipFree.argtypes = [C.c_void_p]
+        self.bufs = []
+
+    def alloc(self, n):
+        p = self.C.c_void_p()
+        assert self.rt.hipMalloc(self.C.byref(p), max(n, 1)) == 0
+        self.bufs.append(p)
+        return p.value
+
+    def to_host(self, ptr, n):
+        out = np.zeros(n, dtype=np.uint8)
+        if n:
+            assert self.rt.hipMemcpy(out.ctypes.data, ptr, n, 2) == 0      # hipMemcpyDeviceToHost
+        return out
+
+    def to_dev(self, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.uint8)
+        p = self.alloc(arr.size)
+        if arr.size:
+            assert self.rt.hipMemcpy(p, arr.ctypes.data, arr.size, 1) == 0  # hipMemcpyHostToDevice
+        return p
+
+    def free(self):
+        for p in self.bufs:
+            self.rt.hipFree(p)
+        self.bufs = []
+
+
+@pytest.mark.parametrize("name,world", [("g2_clean150_k40", 2), ("g5_mixedlen_k21", 3), ("g3_noisy_rep_k21", 2)])
+def test_sharded_contexts_on_one_gpu_match_reference(name, world, tmp_path):
+    """The multi-GPU path without a cluster (SURVEY section 4): `world` rank contexts on ONE GPU, the collectives
+    replaced by explicit concatenation / element-wise max of the very buffers the C ABI exports and imports.
+    Every rank must end with the reference's P.graph3."""
+    from sage2_amd.dist import RECORD_BYTES, EDGE_BYTES, shard_range, max_shard
+    m = fx.golden(name)
+    bases, off = fx.make_reads(m["synth"])
+    hip = _Hip()
+    ctxs = []
+    for r in range(world):
+        c = s2.Context(m["k"], device=0, rank=r, world=world)
+        c.reads_add_ascii(bases, off); c.reads_organize(); c.index_build(); c.overlap_probe_shard()
+        ctxs.append(c)
+    n = ctxs[0].reads_stats().unique_reads
+    ms = max_shard(n, world)
+    sends, planes = [], []
+    for c in ctxs:
+        p = hip.alloc(ms * RECORD_BYTES); c.shard_export_records(p, ms); sends.append(p)
+        q = hip.alloc(c.shard_flags_bytes()); c.shard_export_flags(q); planes.append(hip.to_host(q, c.shard_flags_bytes()))
+    orp = hip.to_dev(np.maximum.reduce(planes))                       # MAX all-reduce == OR of the bit planes
+    for c in ctxs:
+        for r in range(world):
+            lo, hi = shard_range(n, r, world)
+            assert (lo, hi) == ctxs[r].shard_range()
+            if hi > lo:
+                c.shard_import_records(sends[r], lo, hi - lo)
+        c.shard_import_flags(orp)
+        c.overlap_reciprocal()
+    parts = []
+    for c in ctxs:
+        ne = c.shard_edges_count()
+        p = hip.alloc(max(ne, 1) * EDGE_BYTES); c.shard_edges_export(p, max(ne, 1)); parts.append(hip.to_host(p, ne * EDGE_BYTES))
+    allb = np.concatenate(parts); total = allb.size // EDGE_BYTES
+    dall = hip.to_dev(allb)
+    want = fx.golden_graph3(name)
+    for r, c in enumerate(ctxs):
+        c.shard_edges_set(dall if total else 0, total)
+        c.overlap_reduce(); c.overlap_convert()
+        gp = str(tmp_path / f"r{r}.graph3"); c.graph_save(gp)
+        assert open(gp, "rb").read() == want, f"rank {r} differs from the reference"
+        st = c.overlap_stats()
+        assert st.contained_extension == m["counters"]["contained_extension"] and st.contained_size == m["counters"]["contained_size"]
+    for c in ctxs:
+        c.close()
+    hip.free()
+
+
+def test_cli_steps_1_to_3_write_reference_files(tmp_path):
+    import subprocess, os
+    cli = os.path.join(fx.ROOT, "sage2_amd", "sage2ov")
+    m = fx.golden("g6_k70_150")
+    fa = str(tmp_path / "x.fa")
+    s2.synth_write_fasta(fx.synth_params(m["synth"]), fa)
+    out = str(tmp_path / "out")
+    subprocess.run([cli, "-f", fa, "-k", str(m["k"]), "-o", out, "-p", "t", "-M", "3"], check=True)
+    assert fx.md5_file(os.path.join(out, "t.reads")) == m["reads_md5"]
+    assert open(os.path.join(out, "t.graph3"), "rb").read() == fx.golden_graph3("g6_k70_150")
+    # resume from step 2 with -i (main.cpp:63-74): loads P.reads, same graph
+    subprocess.run([cli, "-f", fa, "-k", str(m["k"]), "-o", out, "-p", "u", "-i", "t", "-m", "2", "-M", "3"], check=True)
+    got = open(os.path.join(out, "u.graph3"), "rb").read().split(b"\n", 3)
+    want = fx.golden_graph3("g6_k70_150").split(b"\n", 3)
+    assert got[3] == want[3]          # edge records identical (the 3 header lines need the FASTA totals, which P.reads lacks)
+    assert os.path.exists(os.path.join(out, "t.log"))
