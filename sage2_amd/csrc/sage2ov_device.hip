@@ -52,7 +52,7 @@ struct Device {
     Buf ws[32];
 };
 enum { WS_SLOTS, WS_CNT, WS_WHERE, WS_BIG, WS_CSR, WS_SLOW, WS_NEED, WS_DEG, WS_OFFS, WS_CURSOR, WS_KEYS, WS_KEEP, WS_POS, WS_OWNER, WS_FINAL,
-       WS_PARTIAL, WS_IDS, WS_NEAR, WS_HITS };
+       WS_PARTIAL, WS_IDS, WS_NEAR, WS_HITS, WS_MINH, WS_OCNT, WS_OOFF, WS_OCUR, WS_ORDER };
 static void* ws_get(Device* d, int id, size_t bytes) {
     Device::Buf& b = d->ws[id];
     if (b.cap < bytes || !b.p) {
@@ -152,6 +152,40 @@ __device__ __forceinline__ u64 table_find(const u64* __restrict__ slots, u64 T, 
         if ((s >> SLOT_TAG_SHIFT) == tag) return s;
         if (++idx == T) idx = 0;
     }
+}
+
+// =============================================================================================
+// locality order.  Read ids follow the reference's lexicographic order, i.e. they are random with respect to
+// the genome, so consecutive waves would probe unrelated keys and gather unrelated reads (every access an HBM
+// sector).  Overlapping reads share their windows and their neighbours: processing reads grouped by a
+// locality-sensitive key turns most slot probes and read gathers into L2 hits.  Key = the smallest hashed
+// canonical 16-mer of the read (its "global minimiser"): reads sharing it come from the same ~300 bp of genome.
+// Only the PROCESSING order changes (a permutation of the ids); results do not depend on it.
+// =============================================================================================
+__device__ __forceinline__ u32 mix32(u32 x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
+__global__ void k_minimizer(const u64* __restrict__ reads, u64 lo, u64 hi, int S, u32* minh) {
+    const u64 i = lo + (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= hi) return;
+    const u64* w = reads + i * S;
+    const int L = (int)(w[S - 1] & 0xFFFF);
+    u32 f = 0, r = 0, best = ~0u;
+    u64 cur = 0;
+    for (int p = 0; p < L; p++) {
+        if ((p & 31) == 0) cur = w[p >> 5];
+        const u32 b = (u32)(cur >> 62); cur <<= 2;
+        f = (f << 2) | b; r = (r >> 2) | ((3u - b) << 30);
+        if (p >= 15) { const u32 c = f < r ? f : r; const u32 hsh = mix32(c); best = hsh < best ? hsh : best; }
+    }
+    minh[i - lo] = best;
+}
+__global__ void k_order_count(const u32* __restrict__ minh, u64 n, int shift, u32* cnt) {
+    const u64 x = (u64)blockIdx.x * blockDim.x + threadIdx.x; if (x >= n) return;
+    atomicAdd(&cnt[minh[x] >> shift], 1u);
+}
+__global__ void k_order_fill(const u32* __restrict__ minh, u64 n, u64 lo, int shift, const u32* __restrict__ offs, u32* cursor, u32* order) {
+    const u64 x = (u64)blockIdx.x * blockDim.x + threadIdx.x; if (x >= n) return;
+    const u32 b = minh[x] >> shift; const u32 p = atomicAdd(&cursor[b], 1u);
+    order[offs[b] + p] = (u32)(lo + x);
 }
 
 // =============================================================================================
@@ -596,6 +630,7 @@ __global__ __launch_bounds__(64 * WPB) void k_probe(ProbeArgs A) {
 //   5. DPP wave reductions pick the extension records
 // =============================================================================================
 constexpr int FAST_CAP = 128;
+constexpr int FAST_CHUNK = 64;     // reads per block visit
 template <int S>
 struct FastLds {
     u32 xf[2][2 * S + 2];         // forward, reverse complement as big-endian dwords (+ zero pad)
@@ -654,7 +689,7 @@ __device__ __forceinline__ int first_mismatch(const u32 (&Y)[NW], const u32* E, 
 #define SAGE2OV_FAST_WAVES 5
 #endif
 template <int S, int NW, int WPL, int WPB>
-__global__ __launch_bounds__(64 * WPB, SAGE2OV_FAST_WAVES) void k_probe_fast(ProbeArgs A) {
+__global__ __launch_bounds__(64 * WPB, (SAGE2OV_FAST_WAVES * 4 + WPB - 1) / WPB * WPB / 4 > 4 ? 4 : 4) void k_probe_fast(ProbeArgs A) {
     __shared__ FastLds<S> lds_all[WPB];
     FastLds<S>& L = lds_all[threadIdx.x >> 6];
     const u32 lane = lane_id();
@@ -667,7 +702,19 @@ __global__ __launch_bounds__(64 * WPB, SAGE2OV_FAST_WAVES) void k_probe_fast(Pro
     const u32 lastKeyMask = (2 * h) & 31 ? (~0u << (32 - ((2 * h) & 31))) : ~0u;
     const u32 T32 = (u32)A.T, seed32 = (u32)A.seed;
 
-    for (u64 i = A.lo + wave0; i < A.hi; i += nwaves) {
+    // a block owns FAST_CHUNK consecutive positions of the (locality ordered) id list at a time, so reads that share
+    // keys and neighbours run on one CU, back to back
+    (void)wave0; (void)nwaves;
+    const u64 nItems = A.ids ? A.n_ids : (A.hi > A.lo ? A.hi - A.lo : 0);
+    const u32 wib = threadIdx.x >> 6;
+    for (u64 chunk = blockIdx.x; chunk * FAST_CHUNK < nItems; chunk += gridDim.x)
+    for (u32 t0 = 0; t0 < (u32)FAST_CHUNK; t0 += WPB) {
+        // keep the block's waves on the same group of neighbouring reads: what one wave pulls into L2/L1 the others
+        // use within microseconds (without the barrier the waves drift apart by whole reads and the lines are gone)
+        __syncthreads();
+        const u64 it = chunk * FAST_CHUNK + t0 + wib;
+        if (it >= nItems) continue;
+        const u64 i = A.ids ? (u64)A.ids[it] : A.lo + it;
         // ---------------------------------------------------------------- stage the read (big-endian dwords) + its reverse complement
         wave_sync();
         if (lane < D) L.xf[0][lane] = reads32[i * D + (lane ^ 1)];
@@ -1161,6 +1208,22 @@ static int launch_probe(Device* d, ProbeArgs& A, std::string& err) {
     HIPCHK(hipGetLastError());
     return 0;
 }
+static int scan_u32(Device* d, const u32* in, u64 n, u32* out, u64* total, std::string& err);
+// processing order of ids [lo,hi): grouped by the reads' global minimiser (see k_minimizer)
+static int build_locality_order(Device* d, u64 lo, u64 hi, u32** order_out, std::string& err) {
+    const u64 n = hi - lo;
+    u64 nbk = 1024; while (nbk < n / 16) nbk <<= 1;
+    int lg = 0; while ((1ull << lg) < nbk) lg++;
+    const int shift = 32 - lg;
+    WS(minh, u32, WS_MINH, n); WS(cnt, u32, WS_OCNT, nbk); WS(offs, u32, WS_OOFF, nbk); WS(cur, u32, WS_OCUR, nbk); WS(order, u32, WS_ORDER, n);
+    HIPCHK(hipMemsetAsync(cnt, 0, nbk * sizeof(u32), d->stream)); HIPCHK(hipMemsetAsync(cur, 0, nbk * sizeof(u32), d->stream));
+    hipLaunchKernelGGL(k_minimizer, dim3(grid_for(n, 256)), dim3(256), 0, d->stream, d->reads, (u64)lo, (u64)hi, d->S, minh);
+    hipLaunchKernelGGL(k_order_count, dim3(grid_for(n, 256)), dim3(256), 0, d->stream, minh, (u64)n, shift, cnt);
+    u64 tot = 0; int rc = scan_u32(d, cnt, nbk, offs, &tot, err); if (rc) return rc;
+    hipLaunchKernelGGL(k_order_fill, dim3(grid_for(n, 256)), dim3(256), 0, d->stream, minh, (u64)n, (u64)lo, shift, offs, cur, order);
+    *order_out = order;
+    return 0;
+}
 static ProbeArgs base_args(Device* d) {
     ProbeArgs A; memset(&A, 0, sizeof A);
     A.reads = d->reads; A.N = d->N; A.S = d->S; A.k = d->k; A.h = d->h; A.slots = d->slots; A.T = d->T; A.csr = d->csr; A.seed = d->seed;
@@ -1186,17 +1249,21 @@ int dev_probe(Device* d, uint64_t lo, uint64_t hi, std::string& err) {
         WS(slow, u32, WS_SLOW, nreads);
         A.slow = slow; A.slow_cap = nreads;
         const int nwinMax = d->maxL - d->h + 1;                               // windows of the longest read
-        const unsigned wpb = 4;
-        const unsigned blocks = (unsigned)std::min<u64>((nreads + wpb - 1) / wpb, 256ull * 64);
+        if (!getenv("SAGE2OV_NO_LOCALITY")) { u32* order = nullptr; int rc = build_locality_order(d, lo, hi, &order, err); if (rc) return rc; A.ids = order; A.n_ids = nreads; }
+        const unsigned blocks = (unsigned)std::min<u64>((nreads + FAST_CHUNK - 1) / FAST_CHUNK, 256ull * 16);
         HIPCHK(hipEventRecord(d->ev[2], d->stream));
         bool launched = true;
-        if (d->S == 4 && nwinMax <= 128) launch_fast<4, 8, 2, 4>(d, A, blocks);
-        else if (d->S == 8 && d->maxL <= 160 && nwinMax <= 128) launch_fast<8, 10, 2, 4>(d, A, blocks);
-        else if (d->S == 8 && d->maxL <= 160) launch_fast<8, 10, 4, 4>(d, A, blocks);
-        else if (d->S == 8 && nwinMax <= 128) launch_fast<8, 16, 2, 4>(d, A, blocks);
-        else if (d->S == 8) launch_fast<8, 16, 4, 4>(d, A, blocks);
+#ifndef SAGE2OV_FAST_WPB
+#define SAGE2OV_FAST_WPB 16
+#endif
+        constexpr int FW = SAGE2OV_FAST_WPB;      // waves per block: a whole CU's worth works on one locality chunk
+        if (d->S == 4 && nwinMax <= 128) launch_fast<4, 8, 2, FW>(d, A, blocks);
+        else if (d->S == 8 && d->maxL <= 160 && nwinMax <= 128) launch_fast<8, 10, 2, FW>(d, A, blocks);
+        else if (d->S == 8 && d->maxL <= 160) launch_fast<8, 10, 4, FW>(d, A, blocks);
+        else if (d->S == 8 && nwinMax <= 128) launch_fast<8, 16, 2, FW>(d, A, blocks);
+        else if (d->S == 8) launch_fast<8, 16, 4, FW>(d, A, blocks);
         else launched = false;                                                // 16-word layout: sequential kernel only (for now)
-        if (!launched) { int rc = launch_probe<0>(d, A, err); if (rc) return rc; }
+        if (!launched) { A.ids = nullptr; A.n_ids = 0; int rc = launch_probe<0>(d, A, err); if (rc) return rc; }
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(d->ev[3], d->stream));
         u64 nslow = 0;
