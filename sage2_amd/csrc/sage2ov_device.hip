@@ -112,11 +112,10 @@ __device__ __forceinline__ void rc_key(u64 hi, u64 lo, int h, u64& rhi, u64& rlo
 __device__ __forceinline__ u32 rotl32(u32 x, int r) { return __builtin_amdgcn_alignbit(x, x, 32 - r); }
 #define S2_FINAL(a, b, c) { c ^= b; c -= rotl32(b, 14); a ^= c; a -= rotl32(c, 11); b ^= a; b -= rotl32(a, 25); c ^= b; c -= rotl32(b, 16); \
                             a ^= c; a -= rotl32(c, 4); b ^= a; b -= rotl32(a, 14); c ^= b; c -= rotl32(b, 24); }
-__device__ __forceinline__ u64 hash4(u32 k0, u32 k1, u32 k2, u32 k3, u32 seed) {
+__device__ __forceinline__ u64 hash4(u32 k0, u32 k1, u32 k2, u32 k3, u32 seed, bool four) {
     u32 a = 0xdeadbeefu + seed + k0, b = 0x9e3779b9u + k1, c = 0x7f4a7c15u + k2;
     S2_FINAL(a, b, c);
-    a += k3;
-    S2_FINAL(a, b, c);
+    if (four) { a += k3; S2_FINAL(a, b, c); }          // `four` is uniform: keys longer than 48 bases
     return ((u64)c << 32) | b;
 }
 // (hi,lo) = right-aligned 2h-bit key (the integer of utils.cpp:171-187) -> same hash as the left-aligned dwords
@@ -125,10 +124,11 @@ __device__ __forceinline__ u64 hash_key(u64 hi, u64 lo, int h, u64 seed) {
     if (sh >= 64) { nh = sh == 64 ? lo : (lo << (sh - 64)); nl = 0; }
     else if (sh == 0) { nh = hi; nl = lo; }
     else { nh = (hi << sh) | (lo >> (64 - sh)); nl = lo << sh; }
-    return hash4((u32)(nh >> 32), (u32)nh, (u32)(nl >> 32), (u32)nl, (u32)seed);
+    return hash4((u32)(nh >> 32), (u32)nh, (u32)(nl >> 32), (u32)nl, (u32)seed, 2 * h > 96);
 }
 __device__ __forceinline__ u32 tag_of(u64 hv) { u32 t = (u32)(hv & 0xFFFFFFu); return t ? t : 1u; }
-__device__ __forceinline__ u64 home_of(u64 hv, u64 T) { return (u64)__umulhi((u32)(hv >> 32), (u32)T); }
+// home slot: always even, so that a 16-byte load covers two consecutive slots of the (linear) probe sequence; T is even
+__device__ __forceinline__ u64 home_of(u64 hv, u64 T) { return 2ull * (u64)__umulhi((u32)(hv >> 32), (u32)(T >> 1)); }
 
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -632,20 +632,19 @@ __global__ __launch_bounds__(64 * WPB) void k_probe(ProbeArgs A) {
 constexpr int FAST_CAP = 128;
 constexpr int FAST_CHUNK = 64;     // reads per block visit
 template <int S>
-struct FastLds {
-    u32 xf[2][2 * S + 2];         // forward, reverse complement as big-endian dwords (+ zero pad)
-    u32 e[4][6 * S + 2];          // XR0 = fwd ++ right overhang, XR1 = rc(XR0), XL0 = rc ++ left overhang, XL1 = rc(XL0)
-                                  // (2*maxL bases + NW dwords of read-ahead for first_mismatch)
-    u32 m[2][2 * S + 2];          // the two speculated longest-reach reads
+struct FastLds {                   // every string has one zero dword in front (index 0) so that bit positions down to -32 are readable
+    u32 xf[2][1 + 2 * S + 2];      // forward, reverse complement as big-endian dwords (+ zero pad behind)
+    u32 e[4][1 + 6 * S + 2];       // XR0 = fwd ++ right overhang, XR1 = rc(XR0), XL0 = rc ++ left overhang, XL1 = rc(XL0)
+    u32 m[2][1 + 2 * S + 2];       // the two speculated longest-reach reads
     u32 candJ[FAST_CAP], candSrc[FAST_CAP];
 };
 __device__ __forceinline__ u32 rev2_32(u32 x) { x = __brev(x); return ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1); }
 __device__ __forceinline__ u32 mask_top32(int nb) { return nb >= 16 ? ~0u : (nb <= 0 ? 0u : (~0u << (32 - 2 * nb))); }
 __device__ __forceinline__ u32 range_mask32(int lo, int hi) { return mask_top32(hi) & ~mask_top32(lo); }
 __device__ __forceinline__ u32 funnel32(u32 a, u32 b, int r) { return (u32)(((((u64)a) << 32) | b) >> (32 - r)); }   // r in [0,31]
-// 32 bits at bit position p >= 0 of a big-endian dword string (caller guarantees D[q+1] is readable)
+// 32 bits at bit position p of a big-endian dword string whose dword 0 sits at D[0]; p >= -32 when D[-1] is the zero pad
 __device__ __forceinline__ u32 get32(const u32* D, int p) { const int q = p >> 5; return funnel32(D[q], D[q + 1], p & 31); }
-// same with bounds: anything outside [0, 32*n) reads as zero, p may be negative
+// same with bounds: anything outside [0, 32*n) reads as zero, p may be any negative number (slow, rare paths only)
 __device__ __forceinline__ u32 get32z(const u32* D, int n, int p) {
     const int pp = p < 0 ? 0 : p, sh = pp - p, q = pp >> 5;
     const int q0 = q < n ? q : n - 1, q1 = q + 1 < n ? q + 1 : n - 1;
@@ -667,97 +666,91 @@ __device__ __forceinline__ u32 wave_min_dpp(u32 v) {                 // result v
     return (u32)__builtin_amdgcn_readlane((int)v, 63);
 }
 
-// first mismatching base of Y[0..) against E at base offset d (>= 0); NOMATCH when all NW dwords agree
-constexpr int NOMATCH = 1 << 20;
+// OR of all differences between Y[0..L2) and E at base offset d (>= 0).  cl / tailMask describe L2: dword cl is the
+// partial one, tailMask its valid bits.  When they are wave-uniform the masks cost nothing per dword.
 template <int NW>
-__device__ __forceinline__ int first_mismatch(const u32 (&Y)[NW], const u32* E, int d, int cl, u32 tailMask) {
+__device__ __forceinline__ u32 any_mismatch(const u32 (&Y)[NW], const u32* E, int d, int cl, u32 tailMask) {
     const int q = (2 * d) >> 5, r = (2 * d) & 31;
-    int fm = NOMATCH;
-    u32 nxt = E[q + NW];
+    u32 acc = 0, nxt = E[q + NW];
 #pragma unroll
     for (int c = NW - 1; c >= 0; c--) {
         const u32 cur = E[q + c];
-        u32 diff = Y[c] ^ funnel32(cur, nxt, r);
-        diff &= (c < cl) ? ~0u : (c == cl ? tailMask : 0u);      // bases beyond L2 do not count
-        fm = diff ? 16 * c + (__clz(diff) >> 1) : fm;
+        const u32 diff = Y[c] ^ funnel32(cur, nxt, r);
+        acc |= (c < cl) ? diff : (c == cl ? (diff & tailMask) : 0u);
         nxt = cur;
     }
-    return fm;
+    return acc;
 }
 
-#ifndef SAGE2OV_FAST_WAVES
-#define SAGE2OV_FAST_WAVES 5
+#ifndef SAGE2OV_FAST_WPB
+#define SAGE2OV_FAST_WPB 16
 #endif
 template <int S, int NW, int WPL, int WPB>
-__global__ __launch_bounds__(64 * WPB, (SAGE2OV_FAST_WAVES * 4 + WPB - 1) / WPB * WPB / 4 > 4 ? 4 : 4) void k_probe_fast(ProbeArgs A) {
+__global__ __launch_bounds__(64 * WPB, 4) void k_probe_fast(ProbeArgs A) {
     __shared__ FastLds<S> lds_all[WPB];
     FastLds<S>& L = lds_all[threadIdx.x >> 6];
     const u32 lane = lane_id();
-    const u64 wave0 = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((u64)gridDim.x * blockDim.x) >> 6;
     const int k = A.k, h = A.h;
     constexpr int D = 2 * S;                       // dwords per read slot
-    constexpr int ND = 6 * S + 2;                  // dwords per extended string
+    u32* const X0 = L.xf[0] + 1; u32* const X1 = L.xf[1] + 1;
     const u32* reads32 = (const u32*)A.reads;
     const int nk = (2 * h + 31) >> 5;              // key dwords
+    const bool four = nk > 3;
     const u32 lastKeyMask = (2 * h) & 31 ? (~0u << (32 - ((2 * h) & 31))) : ~0u;
-    const u32 T32 = (u32)A.T, seed32 = (u32)A.seed;
+    const u32 Th = (u32)(A.T >> 1), seed32 = (u32)A.seed;      // T/2 slot pairs
+    const uint4* pairs = (const uint4*)A.slots;
 
     // a block owns FAST_CHUNK consecutive positions of the (locality ordered) id list at a time, so reads that share
     // keys and neighbours run on one CU, back to back
-    (void)wave0; (void)nwaves;
     const u64 nItems = A.ids ? A.n_ids : (A.hi > A.lo ? A.hi - A.lo : 0);
     const u32 wib = threadIdx.x >> 6;
+    if (lane == 0) { L.xf[0][0] = 0; L.xf[1][0] = 0; L.m[0][0] = 0; L.m[1][0] = 0; L.e[0][0] = 0; L.e[1][0] = 0; L.e[2][0] = 0; L.e[3][0] = 0; }
     for (u64 chunk = blockIdx.x; chunk * FAST_CHUNK < nItems; chunk += gridDim.x)
     for (u32 t0 = 0; t0 < (u32)FAST_CHUNK; t0 += WPB) {
-        // keep the block's waves on the same group of neighbouring reads: what one wave pulls into L2/L1 the others
-        // use within microseconds (without the barrier the waves drift apart by whole reads and the lines are gone)
+        // keep the block's waves on the same group of neighbouring reads (what one wave pulls in the others use at once)
         __syncthreads();
         const u64 it = chunk * FAST_CHUNK + t0 + wib;
         if (it >= nItems) continue;
         const u64 i = A.ids ? (u64)A.ids[it] : A.lo + it;
         // ---------------------------------------------------------------- stage the read (big-endian dwords) + its reverse complement
         wave_sync();
-        if (lane < D) L.xf[0][lane] = reads32[i * D + (lane ^ 1)];
-        else if (lane < D + 2) { L.xf[0][lane] = 0; L.xf[1][lane] = 0; }
+        if (lane < D) X0[lane] = reads32[i * D + (lane ^ 1)];
+        else if (lane < D + 2) { X0[lane] = 0; X1[lane] = 0; }
         wave_sync();
-        const int L1 = (int)(L.xf[0][D - 1] & 0xFFFFu);
-        if (lane == 0) L.xf[0][D - 1] &= 0xFFFF0000u;
+        const int L1 = (int)(X0[D - 1] & 0xFFFFu);
+        if (lane == 0) X0[D - 1] &= 0xFFFF0000u;
         wave_sync();
-        if (lane < D) {
-            const int rem = L1 - 16 * (int)lane; u32 r;
-            if (rem <= 0) r = 0;
-            else if (rem >= 16) r = ~rev2_32(get32(L.xf[0], 2 * (rem - 16)));
-            else r = (~rev2_32(L.xf[0][0] >> (32 - 2 * rem))) & mask_top32(rem);
-            L.xf[1][lane] = r;
-        }
+        if (lane < D) { const int rem = L1 - 16 * (int)lane; X1[lane] = rem > 0 ? (~rev2_32(get32(X0, 2 * (rem - 16))) & mask_top32(rem)) : 0u; }
         wave_sync();
         const int nwin = L1 - h + 1;
         bool slowpath = nwin > 64 * WPL;
 
-        // ---------------------------------------------------------------- 1. probes
-        int jj[WPL]; u32 idx[WPL], tg[WPL]; u64 sl[WPL]; bool pend[WPL];
+        // ---------------------------------------------------------------- 1. probes (two slots per 16-byte load)
+        int jj[WPL]; u32 pidx[WPL], tg[WPL]; u64 sl[WPL]; bool pend[WPL];
 #pragma unroll
         for (int q = 0; q < WPL; q++) {
             jj[q] = 64 * q + (int)lane; pend[q] = jj[q] < nwin; sl[q] = 0;
             const int p = 2 * (pend[q] ? jj[q] : 0);
-            u32 k0 = get32(L.xf[0], p), k1 = nk > 1 ? get32(L.xf[0], p + 32) : 0u, k2 = nk > 2 ? get32(L.xf[0], p + 64) : 0u, k3 = nk > 3 ? get32(L.xf[0], p + 96) : 0u;
+            u32 k0 = get32(X0, p), k1 = nk > 1 ? get32(X0, p + 32) : 0u, k2 = nk > 2 ? get32(X0, p + 64) : 0u, k3 = nk > 3 ? get32(X0, p + 96) : 0u;
             if (nk == 1) k0 &= lastKeyMask; else if (nk == 2) k1 &= lastKeyMask; else if (nk == 3) k2 &= lastKeyMask; else k3 &= lastKeyMask;
-            const u64 hv = hash4(k0, k1, k2, k3, seed32);
-            idx[q] = __umulhi((u32)(hv >> 32), T32); tg[q] = tag_of(hv);
+            const u64 hv = hash4(k0, k1, k2, k3, seed32, four);
+            pidx[q] = __umulhi((u32)(hv >> 32), Th); tg[q] = tag_of(hv);
         }
         for (;;) {
             bool any = false;
 #pragma unroll
             for (int q = 0; q < WPL; q++) any |= pend[q];
             if (!__any(any)) break;
-            u64 sv[WPL];
+            uint4 pv[WPL];
 #pragma unroll
-            for (int q = 0; q < WPL; q++) sv[q] = A.slots[idx[q]];              // unconditional: idle lanes re-read their last slot
+            for (int q = 0; q < WPL; q++) pv[q] = pairs[pidx[q]];               // unconditional: idle lanes re-read their last pair
 #pragma unroll
             for (int q = 0; q < WPL; q++) {
                 if (pend[q]) {
-                    if (sv[q] == 0 || (u32)(sv[q] >> SLOT_TAG_SHIFT) == tg[q]) { sl[q] = sv[q]; pend[q] = false; }
-                    else if (++idx[q] == T32) idx[q] = 0;
+                    const u64 s0 = ((u64)pv[q].y << 32) | pv[q].x, s1 = ((u64)pv[q].w << 32) | pv[q].z;
+                    if (s0 == 0 || (pv[q].y >> (SLOT_TAG_SHIFT - 32)) == tg[q]) { sl[q] = s0; pend[q] = false; }
+                    else if (s1 == 0 || (pv[q].w >> (SLOT_TAG_SHIFT - 32)) == tg[q]) { sl[q] = s1; pend[q] = false; }
+                    else if (++pidx[q] == Th) pidx[q] = 0;
                 }
             }
         }
@@ -809,92 +802,78 @@ __global__ __launch_bounds__(64 * WPB, (SAGE2OV_FAST_WAVES * 4 + WPB - 1) / WPB 
                 if (NW == D) Y[q][NW - 1] &= 0xFFFF0000u;
             }
             // ---------------------------------------------------------------- 3. speculation: furthest reach per side
-            u32 reachR = ~0u, reachL = ~0u;
+            u32 reachR = ~0u, reachL = ~0u; bool sameLen = true;
 #pragma unroll
             for (int q = 0; q < 2; q++) {
                 if (gate[q]) {
                     const int t = myEnt[q] & 3; const u32 ci = lane + 64 * q;
                     if (t == 0 || t == 2) reachR = min(reachR, ((u32)(0x7FF - (myJ[q] + myL2[q])) << 7) | ci);
                     else reachL = min(reachL, ((u32)(0x7FF - (L1 - myJ[q] - h + myL2[q])) << 7) | ci);
+                    sameLen &= (myL2[q] == L1);
                 }
             }
             reachR = wave_min_dpp(reachR); reachL = wave_min_dpp(reachL);
-            // the two speculated reads verify their overlap and publish themselves; per-side parameters for the builders
-            int LR = 0, LL = 0; bool specFail = false;
-            (void)LR; (void)LL;
+            const bool uniformLen = __all(sameLen);
+            // (t, j, L2) of the two speculated reads, broadcast with readlane (EXEC independent); they publish their bases
+            u32 mEnt[2] = {0, 0}; int mJ[2] = {0, 0}, mL2[2] = {0, 0};
 #pragma unroll
-            for (int q = 0; q < 2; q++) {
-                const u32 ci = lane + 64 * q;
-                const bool isMR = reachR != ~0u && (reachR & 127u) == ci, isML = reachL != ~0u && (reachL & 127u) == ci;
-                if (isMR || isML) {
-                    const int t = myEnt[q] & 3, j = myJ[q], L2 = myL2[q];
-                    const int span = isMR ? (L1 - j) : (j + h); const int n = L2 < span ? L2 : span;
-                    // overlap region only: Y[b] == X[b+d] for b in [lo,hi)
-                    const u32* X = (t == 0 || t == 1) ? L.xf[0] : L.xf[1];
-                    int d, lo, hi;
-                    if (t == 0) { d = j; lo = 0; hi = n; } else if (t == 3) { d = L1 - j - h; lo = 0; hi = n; }
-                    else if (t == 2) { d = L1 - j - L2; lo = L2 - n; hi = L2; } else { d = j + h - L2; lo = L2 - n; hi = L2; }
-                    u32 diff = 0;
+            for (int sd = 0; sd < 2; sd++) {
+                const u32 rk = sd ? reachL : reachR;
+                if (rk != ~0u) {
+                    const int ol = (int)(rk & 63u); const bool oq = ((rk >> 6) & 1u) != 0;
+                    mEnt[sd] = (u32)__builtin_amdgcn_readlane((int)(oq ? myEnt[1] : myEnt[0]), ol);
+                    mJ[sd] = __builtin_amdgcn_readlane(oq ? myJ[1] : myJ[0], ol);
+                    mL2[sd] = __builtin_amdgcn_readlane(oq ? myL2[1] : myL2[0], ol);
+                    if ((int)lane == ol) {
+                        u32* M = L.m[sd] + 1;
 #pragma unroll
-                    for (int c = 0; c < NW; c++) diff |= (Y[q][c] ^ get32z(X, D + 2, 2 * (16 * c + d))) & range_mask32(lo - 16 * c, hi - 16 * c);
-                    if (diff != 0 || L2 <= span) specFail = true;       // not a proper overlap: let the sequential kernel sort it out
-                    u32* M = L.m[isMR ? 0 : 1];
+                        for (int c = 0; c < NW; c++) M[c] = oq ? Y[1][c] : Y[0][c];
 #pragma unroll
-                    for (int c = 0; c < NW; c++) M[c] = Y[q][c];
-#pragma unroll
-                    for (int c = NW; c < D + 2; c++) M[c] = 0;
-                }
-            }
-            if (__any(specFail)) slowpath = true;
-            wave_sync();
-            if (!slowpath) {
-                // ---- extended strings: lanes 0-31 build the right side, lanes 32-63 the left side
-                // (t, j, L2) of the two speculated reads, broadcast with readlane (EXEC independent)
-                u32 mEnt[2] = {0, 0}; int mJ[2] = {0, 0}, mL2[2] = {0, 0};
-#pragma unroll
-                for (int sd = 0; sd < 2; sd++) {
-                    const u32 rk = sd ? reachL : reachR;
-                    if (rk != ~0u) {
-                        const int ol = (int)(rk & 63u); const bool oq = ((rk >> 6) & 1u) != 0;
-                        mEnt[sd] = (u32)__builtin_amdgcn_readlane((int)(oq ? myEnt[1] : myEnt[0]), ol);
-                        mJ[sd] = __builtin_amdgcn_readlane(oq ? myJ[1] : myJ[0], ol);
-                        mL2[sd] = __builtin_amdgcn_readlane(oq ? myL2[1] : myL2[0], ol);
+                        for (int c = NW; c < D + 2; c++) M[c] = 0;
                     }
                 }
-                LR = reachR != ~0u ? mJ[0] + mL2[0] : 0;
-                LL = reachL != ~0u ? (L1 - mJ[1] - h) + mL2[1] : 0;
+            }
+            const int posR = mJ[0], posL = L1 - mJ[1] - h;                                  // offsets in the side's own coordinates
+            const int LR = reachR != ~0u ? posR + mL2[0] : 0, LL = reachL != ~0u ? posL + mL2[1] : 0;
+            // a speculated read that ends inside this read (containment) or that does not reach its end is left to the sequential kernel
+            if ((reachR != ~0u && LR <= L1) || (reachL != ~0u && LL <= L1)) slowpath = true;
+            wave_sync();
+            if (!slowpath) {
+                // ---- extended strings: lanes 0-31 build the right side, lanes 32-63 the left side, one dword per lane
                 {
                     const int side = lane >> 5, c = (int)(lane & 31);
                     const u32 rk = side ? reachL : reachR;
+                    bool mbad = false;
                     if (rk != ~0u) {
-                        const int t = (side ? mEnt[1] : mEnt[0]) & 3, L2M = side ? mL2[1] : mL2[0];
-                        const int posM = side ? (L1 - mJ[1] - h) : mJ[0];            // offset of the read in its side's coordinates
-                        const int tot = posM + L2M;
-                        // straight: own strand [0,posM) ++ M ; mirrored: M ++ other strand [L1-posM, L1)
+                        const int t = (side ? mEnt[1] : mEnt[0]) & 3, L2M = side ? mL2[1] : mL2[0], posM = side ? posL : posR, tot = posM + L2M;
                         const bool straight = side ? (t == 3) : (t == 0);
-                        const u32* own = side ? L.xf[1] : L.xf[0]; const u32* oth = side ? L.xf[0] : L.xf[1];
-                        u32* dstA = L.e[2 * side + (straight ? 0 : 1)]; u32* dstB = L.e[2 * side + (straight ? 1 : 0)];
-                        const u32* Aa = straight ? own : L.m[side]; const int lenA = straight ? posM : L2M;
-                        const u32* Bb = straight ? L.m[side] : oth; const int bStart = straight ? 0 : (L1 - posM), lenB = straight ? L2M : posM;
-                        for (int cc = c; cc < ND; cc += 32) {
-                            const int cb = 16 * cc;
-                            const u32 va = get32z(Aa, D + 2, 2 * cb) & range_mask32(0 - cb, lenA - cb);
-                            const u32 vb = get32z(Bb, D + 2, 2 * (cb - lenA + bStart)) & range_mask32(lenA - cb, lenA + lenB - cb);
-                            dstA[cc] = va | vb;
-                        }
+                        const u32* own = side ? X1 : X0; const u32* oth = side ? X0 : X1; const u32* M = L.m[side] + 1;
+                        u32* dstA = L.e[2 * side + (straight ? 0 : 1)] + 1; u32* dstB = L.e[2 * side + (straight ? 1 : 0)] + 1;
+                        // straight: own[0,posM) ++ M ; mirrored: M ++ other strand [L1-posM, L1).  B is shifted right by sB >= 0 bases.
+                        const u32* Aa = straight ? own : M; const int lenA = straight ? posM : L2M;
+                        const u32* Bb = straight ? M : oth; const int sB = straight ? posM : (tot - L1);
+                        const int cb = 16 * c;
+                        const int pB = 2 * (cb - sB);                                       // bit position in B; >= -32 is readable (front pad)
+                        const u32 va = Aa[c];
+                        const u32 vb = pB >= -32 ? get32(Bb, pB) : 0u;
+                        const u32 mA = mask_top32(lenA - cb);
+                        dstA[c] = ((va & mA) | (vb & ~mA)) & mask_top32(tot - cb);
                         wave_sync();
-                        for (int cc = c; cc < ND; cc += 32) {
-                            const int rem = tot - 16 * cc; u32 r;
-                            if (rem <= 0) r = 0;
-                            else if (rem >= 16) r = ~rev2_32(get32z(dstA, ND, 2 * (rem - 16)));
-                            else r = (~rev2_32(dstA[0] >> (32 - 2 * rem))) & mask_top32(rem);
-                            dstB[cc] = r;
-                        }
-                    }
+                        const int rem = tot - cb;
+                        dstB[c] = rem > 0 ? (~rev2_32(get32(dstA, 2 * (rem - 16))) & mask_top32(rem)) : 0u;
+                        wave_sync();
+                        // the speculated read must really overlap: the straight string equals the own strand on [posM, L1)
+                        const u32* Es = L.e[2 * side] + 1;
+                        mbad = ((Es[c] ^ own[c]) & range_mask32(posM - cb, L1 - cb)) != 0 && c < D + 2;
+                    } else { wave_sync(); wave_sync(); }
+                    if (__any(mbad)) slowpath = true;
                 }
                 wave_sync();
+            }
+            if (!slowpath) {
                 // ---------------------------------------------------------------- 4. one whole-length compare per candidate
                 bool bad = false;
+                const int clU = L1 >> 4; const u32 tailU = mask_top32(L1 & 15);
 #pragma unroll
                 for (int q = 0; q < 2; q++) {
                     bool hit = false;
@@ -904,16 +883,15 @@ __global__ __launch_bounds__(64 * WPB, (SAGE2OV_FAST_WAVES * 4 + WPB - 1) / WPB 
                         const int span = rightSide ? (L1 - j) : (j + h);
                         const bool cont = L2 <= span; const int n = cont ? L2 : span;
                         const int off = L1 - j - h;
-                        const u32* E = L.e[t == 0 ? 0 : (t == 2 ? 1 : (t == 3 ? 2 : 3))];
-                        // a contained read (or one reaching past the speculated end: impossible) cannot use the extended string
+                        const u32* E = L.e[t == 0 ? 0 : (t == 2 ? 1 : (t == 3 ? 2 : 3))] + 1;
                         const int d = t == 0 ? j : (t == 2 ? LR - j - L2 : (t == 3 ? off : LL - off - L2));
                         const bool usable = !cont && d >= 0;
-                        int fm = NOMATCH;
-                        if (usable) fm = first_mismatch<NW>(Y[q], E, d, L2 >> 4, mask_top32(L2 & 15));
-                        if (usable && fm == NOMATCH) hit = true;                                   // verified and consistent
+                        u32 acc = 1;
+                        if (usable) acc = uniformLen ? any_mismatch<NW>(Y[q], E, d, clU, tailU) : any_mismatch<NW>(Y[q], E, d, L2 >> 4, mask_top32(L2 & 15));
+                        if (acc == 0) hit = true;                                                  // verified and consistent
                         else {
                             // rare: decide between "not an overlap" and "overlap, but inconsistent / contained"
-                            const u32* X = (t == 0 || t == 1) ? L.xf[0] : L.xf[1];
+                            const u32* X = (t == 0 || t == 1) ? X0 : X1;
                             int dd, lo, hi;
                             if (t == 0) { dd = j; lo = 0; hi = n; } else if (t == 3) { dd = off; lo = 0; hi = n; }
                             else if (t == 2) { dd = L1 - j - L2; lo = L2 - n; hi = L2; } else { dd = j + h - L2; lo = L2 - n; hi = L2; }
@@ -1128,7 +1106,7 @@ int dev_upload_reads(Device* d, const uint64_t* words, uint64_t N, int S, int ma
 int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t* csr_out, uint64_t* nlong_out, uint32_t* rebuilds, std::string& err) {
     HIPCHK(hipSetDevice(d->ordinal));
     const u64 N = d->N; if (!d->reads) { err = "reads not resident"; return SAGE2OV_ERR_ARG; }
-    d->T = std::max<u64>(1024, 8 * N);                                   // load <= 0.5, as hashTable.cpp:83 sizes it
+    d->T = std::max<u64>(1024, 8 * N);                                   // load <= 0.5, as hashTable.cpp:83 sizes it (even: pairs)
     if (d->T >= (1ull << 32)) { err = "table too large for 32-bit slot indices"; return SAGE2OV_ERR_LIMIT; }
     const u32 big_cap = 1u << 20;
     WS(slots_ws, u64, WS_SLOTS, d->T); d->slots = slots_ws;
@@ -1253,9 +1231,6 @@ int dev_probe(Device* d, uint64_t lo, uint64_t hi, std::string& err) {
         const unsigned blocks = (unsigned)std::min<u64>((nreads + FAST_CHUNK - 1) / FAST_CHUNK, 256ull * 16);
         HIPCHK(hipEventRecord(d->ev[2], d->stream));
         bool launched = true;
-#ifndef SAGE2OV_FAST_WPB
-#define SAGE2OV_FAST_WPB 16
-#endif
         constexpr int FW = SAGE2OV_FAST_WPB;      // waves per block: a whole CU's worth works on one locality chunk
         if (d->S == 4 && nwinMax <= 128) launch_fast<4, 8, 2, FW>(d, A, blocks);
         else if (d->S == 8 && d->maxL <= 160 && nwinMax <= 128) launch_fast<8, 10, 2, FW>(d, A, blocks);
