@@ -38,6 +38,7 @@ struct Device {
     // index
     u64 T = 0; u64* slots = nullptr; u32* csr = nullptr; u64 n_csr = 0; u64 seed = 0x5A6E2D0Full;
     u64 n_keys = 0, n_long = 0;
+    u64* mi1 = nullptr; u64 TL = 0; u64* krec = nullptr; u64 n_groups = 0;      // minimiser index (fast kernel)
     // per-read results
     u64* right = nullptr; u64* left = nullptr; u32* conn = nullptr; u32* cflag = nullptr; uint8_t* status = nullptr;
     // edge candidates
@@ -52,7 +53,7 @@ struct Device {
     Buf ws[32];
 };
 enum { WS_SLOTS, WS_CNT, WS_WHERE, WS_BIG, WS_CSR, WS_SLOW, WS_NEED, WS_DEG, WS_OFFS, WS_CURSOR, WS_KEYS, WS_KEEP, WS_POS, WS_OWNER, WS_FINAL,
-       WS_PARTIAL, WS_IDS, WS_NEAR, WS_HITS, WS_MINH, WS_OCNT, WS_OOFF, WS_OCUR, WS_ORDER };
+       WS_PARTIAL, WS_IDS, WS_NEAR, WS_HITS, WS_MINH, WS_OCNT, WS_OOFF, WS_OCUR, WS_ORDER, WS_MI1, WS_MICNT, WS_MICUR, WS_KREC, WS_SLOTMH };
 static void* ws_get(Device* d, int id, size_t bytes) {
     Device::Buf& b = d->ws[id];
     if (b.cap < bytes || !b.p) {
@@ -127,6 +128,37 @@ __device__ __forceinline__ u64 hash_key(u64 hi, u64 lo, int h, u64 seed) {
     return hash4((u32)(nh >> 32), (u32)nh, (u32)(nl >> 32), (u32)nl, (u32)seed, 2 * h > 96);
 }
 __device__ __forceinline__ u32 tag_of(u64 hv) { u32 t = (u32)(hv & 0xFFFFFFu); return t ? t : 1u; }
+// ---- minimiser index (second access path used by the fast kernel): distinct keys grouped by their minimiser
+// (smallest hashed w-mer of the key, w = min(16,h)).  The ~13 consecutive windows of a read that share a minimiser
+// find their keys in ONE contiguous group instead of 13 random sectors of the uniform table.
+__device__ __forceinline__ u32 mix32(u32 x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
+__device__ __forceinline__ u32 wmer_hash(u32 wm) { wm *= 0x9E3779B1u; return wm ^ (wm >> 15); }        // order of w-mers (one multiply)
+__device__ __forceinline__ u32 minim_hash(u32 minh, u32 seed) { return mix32(minh ^ (seed * 0x85EBCA77u + 0x165667B1u)); }   // uniform 32 bits
+__device__ __forceinline__ u32 minim_tag(u32 mh) { u32 t = mix32(mh + 0x2545F491u) & 0xFFFFFFu; return t ? t : 1u; }
+__device__ __forceinline__ u32 funnel32k(u32 a, u32 b, int r) { return (u32)(((((u64)a) << 32) | b) >> (32 - r)); }
+// smallest w-mer hash of a left-aligned h-base key (dwords k0..k3)
+__device__ __forceinline__ u32 key_min_hash(u32 k0, u32 k1, u32 k2, u32 k3, int h) {
+    const int w = h < 16 ? h : 16, m = h - w + 1;
+    u32 best = ~0u;
+    for (int p = 0; p < m; p++) {
+        const int q = (2 * p) >> 5, r = (2 * p) & 31;
+        const u32 a = q == 0 ? k0 : (q == 1 ? k1 : (q == 2 ? k2 : k3));
+        const u32 b = q == 0 ? k1 : (q == 1 ? k2 : (q == 2 ? k3 : 0u));
+        const u32 wm = funnel32k(a, b, r) >> (32 - 2 * w);
+        const u32 hh = wmer_hash(wm);
+        best = hh < best ? hh : best;
+    }
+    return best;
+}
+// left-aligned dwords of a right-aligned (hi,lo) key
+__device__ __forceinline__ void key_left_align(u64 hi, u64 lo, int h, u32& k0, u32& k1, u32& k2, u32& k3) {
+    const int sh = 128 - 2 * h; u64 nh, nl;
+    if (sh >= 64) { nh = sh == 64 ? lo : (lo << (sh - 64)); nl = 0; }
+    else if (sh == 0) { nh = hi; nl = lo; }
+    else { nh = (hi << sh) | (lo >> (64 - sh)); nl = lo << sh; }
+    k0 = (u32)(nh >> 32); k1 = (u32)nh; k2 = (u32)(nl >> 32); k3 = (u32)nl;
+}
+constexpr u32 MI_BIG = 255;      // group too large or ambiguous: its windows use the uniform table
 // home slot: always even, so that a 16-byte load covers two consecutive slots of the (linear) probe sequence; T is even
 __device__ __forceinline__ u64 home_of(u64 hv, u64 T) { return 2ull * (u64)__umulhi((u32)(hv >> 32), (u32)(T >> 1)); }
 
@@ -162,7 +194,6 @@ __device__ __forceinline__ u64 table_find(const u64* __restrict__ slots, u64 T, 
 // canonical 16-mer of the read (its "global minimiser"): reads sharing it come from the same ~300 bp of genome.
 // Only the PROCESSING order changes (a permutation of the ids); results do not depend on it.
 // =============================================================================================
-__device__ __forceinline__ u32 mix32(u32 x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
 __global__ void k_minimizer(const u64* __restrict__ reads, u64 lo, u64 hi, int S, u32* minh) {
     const u64 i = lo + (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= hi) return;
@@ -286,15 +317,21 @@ __global__ __launch_bounds__(256) void k_index_alloc(u64* slots, u64 T, const u3
         }
     }
 }
-__global__ void k_index_fill(u64 N, u64* slots, u32* cnt, const u32* __restrict__ where, u32* csr) {
+__global__ void k_index_fill(const u64* __restrict__ reads, u64 N, int S, int h, u32 seed, u64* slots, u32* cnt, const u32* __restrict__ where, u32* csr, u32* slot_mh) {
     u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     const u64 stride = (u64)gridDim.x * blockDim.x;
     for (; e < 4 * N; e += stride) {
         u64 idx = where[e]; u64 s = slots[idx];
         u32 c7 = (u32)(s >> SLOT_CNT_SHIFT) & 127u;
         u32 entry = (u32)(((e >> 2) + 1) * 4 + (e & 3));
-        if (c7 == 0) slots[idx] = (s & (~0ull << SLOT_TAG_SHIFT)) | (1ull << SLOT_CNT_SHIFT) | entry;   // the only entry: inline
-        else { u32 pos = atomicSub(&cnt[idx], 1u) - 1u; csr[(s & SLOT_PAY_MASK) + pos] = entry; }
+        bool designated;
+        if (c7 == 0) { slots[idx] = (s & (~0ull << SLOT_TAG_SHIFT)) | (1ull << SLOT_CNT_SHIFT) | entry; designated = true; }   // the only entry: inline
+        else { u32 pos = atomicSub(&cnt[idx], 1u) - 1u; csr[(s & SLOT_PAY_MASK) + pos] = entry; designated = pos == 0; }
+        if (slot_mh && designated) {                                   // one entry per bucket: minimiser of the bucket's key (stage B)
+            u64 hi, lo; entry_key(reads, S, h, (e >> 2) + 1, (int)(e & 3), hi, lo);
+            u32 k0, k1, k2, k3; key_left_align(hi, lo, h, k0, k1, k2, k3);
+            slot_mh[idx] = minim_hash(key_min_hash(k0, k1, k2, k3, h), seed);
+        }
     }
 }
 __global__ void k_index_sort(const u64* __restrict__ slots, u64 T, u32* csr) {
@@ -317,6 +354,63 @@ __global__ void k_index_purity(const u64* __restrict__ reads, int S, int h, cons
     if (__ballot(bad)) { if (lane_id() == 0) atomicAdd(&counters[3], 1ull); }
     else if (lane_id() == 0) atomicAdd(&counters[4], 1ull);
 }
+// ---- stage B of the index build: group the distinct-key records of the uniform table by minimiser
+__device__ __forceinline__ u64 mi_find_or_claim(u64* mi1, u64 TL, u32 mh, bool claim) {
+    const u64 mt = minim_tag(mh); u64 idx = __umulhi(mh, (u32)TL);
+    for (;;) {
+        u64 v = __hip_atomic_load(&mi1[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v == 0) {
+            if (!claim) return ~0ull;
+            const u64 old = atomicCAS((u64*)&mi1[idx], 0ull, mt << SLOT_TAG_SHIFT);
+            if (old == 0 || (old >> SLOT_TAG_SHIFT) == mt) return idx;
+        } else if ((v >> SLOT_TAG_SHIFT) == mt) return idx;
+        if (++idx == TL) idx = 0;
+    }
+}
+__global__ void k_mi_count(const u64* __restrict__ slots, u64 T, const u32* __restrict__ slot_mh, u64* mi1, u64 TL, u32* mcnt) {
+    const u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x; if (idx >= T) return;
+    const u64 s = slots[idx]; if (s == 0) return;
+    const u64 g = mi_find_or_claim(mi1, TL, slot_mh[idx], true);
+    atomicAdd(&mcnt[g], 1u);
+}
+__global__ __launch_bounds__(256) void k_mi_alloc(u64* mi1, u64 TL, const u32* __restrict__ mcnt, u64* counters) {   // counters[5]: records placed, [6]: groups
+    __shared__ u32 sh[4]; __shared__ u64 shBase;
+    const u64 base0 = (u64)blockIdx.x * ALLOC_ITEMS;
+    u32 c[ALLOC_PER_THREAD]; u32 need = 0, occ = 0;
+#pragma unroll
+    for (int x = 0; x < ALLOC_PER_THREAD; x++) { const u64 idx = base0 + (u64)x * 256 + threadIdx.x; c[x] = idx < TL ? mcnt[idx] : 0u; need += c[x]; occ += c[x] != 0; }
+    u32 total; const u32 excl = block_excl_scan(need, sh, total);
+    u32 occTotal; block_excl_scan(occ, sh, occTotal);
+    if (threadIdx.x == 0) { shBase = total ? atomicAdd(&counters[5], (u64)total) : 0ull; if (occTotal) atomicAdd(&counters[6], (u64)occTotal); }
+    __syncthreads();
+    u64 start = shBase + excl;
+#pragma unroll
+    for (int x = 0; x < ALLOC_PER_THREAD; x++) {
+        if (c[x]) {
+            const u64 idx = base0 + (u64)x * 256 + threadIdx.x;
+            mi1[idx] = (mi1[idx] & (~0ull << SLOT_TAG_SHIFT)) | ((u64)(c[x] >= MI_BIG ? MI_BIG : c[x]) << 32) | start;
+            start += c[x];
+        }
+    }
+}
+__global__ void k_mi_fill(const u64* __restrict__ slots, u64 T, const u32* __restrict__ slot_mh, u64* mi1, u64 TL, u32* mcur, u64* krec) {
+    const u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x; if (idx >= T) return;
+    const u64 s = slots[idx]; if (s == 0) return;
+    const u64 g = mi_find_or_claim(mi1, TL, slot_mh[idx], false);
+    const u64 v = mi1[g];
+    if (((v >> 32) & 255u) == MI_BIG) return;                       // oversized group: never scanned
+    const u32 pos = atomicAdd(&mcur[g], 1u);
+    krec[(u32)v + pos] = s;
+}
+// a group in which two records share a tag cannot be scanned unambiguously: send its windows to the uniform table
+__global__ void k_mi_check(u64* mi1, u64 TL, const u64* __restrict__ krec) {
+    const u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x; if (g >= TL) return;
+    const u64 v = mi1[g]; const u32 n = (u32)(v >> 32) & 255u; if (v == 0 || n < 2 || n == MI_BIG) return;
+    const u64* r = krec + (u32)v; bool dup = false;
+    for (u32 a = 1; a < n && !dup; a++) for (u32 b = 0; b < a; b++) if ((r[a] >> SLOT_TAG_SHIFT) == (r[b] >> SLOT_TAG_SHIFT)) { dup = true; break; }
+    if (dup) mi1[g] = (v & ~(0xFFull << 32)) | ((u64)MI_BIG << 32);
+}
+
 __global__ void k_lookup(const u64* __restrict__ slots, u64 T, const u32* __restrict__ csr, u64 seed, int h, u64 hi, u64 lo, u64* out, u32 cap) {
     u64 s = table_find(slots, T, hash_key(hi, lo, h, seed));
     u32 c7 = (u32)(s >> SLOT_CNT_SHIFT) & 127u;
@@ -413,6 +507,7 @@ struct ProbeArgs {
     u64* right; u64* left; u32* conn; u32* cflag;         // MODE 0 outputs
     const uint8_t* status; Hit* hits; u64 hits_cap; u64* counters;   // MODE 1
     const u32* ids; u64 n_ids;                             // optional explicit read list (replaces [lo,hi))
+    const u64* mi1; u64 TL; const u64* krec;               // minimiser index (may be null)
     u32* slow; u64 slow_cap;                               // fast kernel: reads handed to the sequential kernel (count in counters[6])
 };
 
@@ -637,6 +732,7 @@ struct FastLds {                   // every string has one zero dword in front (
     u32 e[4][1 + 6 * S + 2];       // XR0 = fwd ++ right overhang, XR1 = rc(XR0), XL0 = rc ++ left overhang, XL1 = rc(XL0)
     u32 m[2][1 + 2 * S + 2];       // the two speculated longest-reach reads
     u32 candJ[FAST_CAP], candSrc[FAST_CAP];
+    u32 wh[2][32 * S];             // w-mer hashes of the read and the ping-pong buffer of the sliding minimum
 };
 __device__ __forceinline__ u32 rev2_32(u32 x) { x = __brev(x); return ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1); }
 __device__ __forceinline__ u32 mask_top32(int nb) { return nb >= 16 ? ~0u : (nb <= 0 ? 0u : (~0u << (32 - 2 * nb))); }
@@ -683,7 +779,7 @@ __device__ __forceinline__ u32 any_mismatch(const u32 (&Y)[NW], const u32* E, in
 }
 
 #ifndef SAGE2OV_FAST_WPB
-#define SAGE2OV_FAST_WPB 16
+#define SAGE2OV_FAST_WPB 8
 #endif
 template <int S, int NW, int WPL, int WPB>
 __global__ __launch_bounds__(64 * WPB, 4) void k_probe_fast(ProbeArgs A) {
@@ -708,7 +804,9 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_probe_fast(ProbeArgs A) {
     for (u64 chunk = blockIdx.x; chunk * FAST_CHUNK < nItems; chunk += gridDim.x)
     for (u32 t0 = 0; t0 < (u32)FAST_CHUNK; t0 += WPB) {
         // keep the block's waves on the same group of neighbouring reads (what one wave pulls in the others use at once)
-        __syncthreads();
+#ifdef SAGE2OV_LOCKSTEP
+        __syncthreads();       // (measured: lock step costs more than the L2 sharing it buys once the minimiser index is in place)
+#endif
         const u64 it = chunk * FAST_CHUNK + t0 + wib;
         if (it >= nItems) continue;
         const u64 i = A.ids ? (u64)A.ids[it] : A.lo + it;
@@ -725,7 +823,7 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_probe_fast(ProbeArgs A) {
         const int nwin = L1 - h + 1;
         bool slowpath = nwin > 64 * WPL;
 
-        // ---------------------------------------------------------------- 1. probes (two slots per 16-byte load)
+        // ---------------------------------------------------------------- 1. lookups
         int jj[WPL]; u32 pidx[WPL], tg[WPL]; u64 sl[WPL]; bool pend[WPL];
 #pragma unroll
         for (int q = 0; q < WPL; q++) {
@@ -736,6 +834,75 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_probe_fast(ProbeArgs A) {
             const u64 hv = hash4(k0, k1, k2, k3, seed32, four);
             pidx[q] = __umulhi((u32)(hv >> 32), Th); tg[q] = tag_of(hv);
         }
+        if (A.mi1) {
+            // 1a. minimiser of every window: hash all w-mers once, then a sliding minimum of width m = h-w+1 by doubling
+            u32 winMin[WPL];
+            {
+                const int w = h < 16 ? h : 16, m = h - w + 1, npos = L1 - w + 1;
+                constexpr int NP = 32 * S;
+                for (int p0 = (int)lane; p0 < NP; p0 += 64) L.wh[0][p0] = p0 < npos ? wmer_hash(get32(X0, 2 * p0) >> (32 - 2 * w)) : ~0u;
+                wave_sync();
+#pragma unroll
+                for (int q = 0; q < WPL; q++) winMin[q] = ~0u;
+                int cur = 0, off = 0;
+                for (int bit = 0; (1 << bit) <= m; bit++) {
+                    if (m & (1 << bit)) {
+#pragma unroll
+                        for (int q = 0; q < WPL; q++) { const int p0 = 64 * q + (int)lane + off; winMin[q] = min(winMin[q], L.wh[cur][p0 < NP ? p0 : NP - 1]); }
+                        off += 1 << bit;
+                    }
+                    if ((2 << bit) <= m) {       // next level: width doubles
+                        for (int p0 = (int)lane; p0 < NP; p0 += 64) { const int p1 = p0 + (1 << bit); L.wh[cur ^ 1][p0] = min(L.wh[cur][p0], L.wh[cur][p1 < NP ? p1 : NP - 1]); }
+                        wave_sync();
+                        cur ^= 1;
+                    }
+                }
+            }
+            // 1b. group of the minimiser (lanes that share a minimiser read the same words), then a scan of the group
+            u32 goff[WPL], gn[WPL]; const u32 TL32 = (u32)A.TL;
+            {
+                u32 gi[WPL], mt[WPL]; bool gp[WPL];
+#pragma unroll
+                for (int q = 0; q < WPL; q++) { const u32 mh = minim_hash(winMin[q], seed32); gi[q] = __umulhi(mh, TL32); mt[q] = minim_tag(mh); gp[q] = pend[q]; goff[q] = 0; gn[q] = 0; }
+                for (;;) {
+                    bool any = false;
+#pragma unroll
+                    for (int q = 0; q < WPL; q++) any |= gp[q];
+                    if (!__any(any)) break;
+                    u64 gv[WPL];
+#pragma unroll
+                    for (int q = 0; q < WPL; q++) gv[q] = A.mi1[gi[q]];
+#pragma unroll
+                    for (int q = 0; q < WPL; q++) {
+                        if (gp[q]) {
+                            if (gv[q] == 0) { gp[q] = false; pend[q] = false; }                              // no key has this minimiser: a miss
+                            else if ((u32)(gv[q] >> SLOT_TAG_SHIFT) == mt[q]) { gp[q] = false; gn[q] = (u32)(gv[q] >> 32) & 255u; goff[q] = (u32)gv[q]; }
+                            else if (++gi[q] == TL32) gi[q] = 0;
+                        }
+                    }
+                }
+            }
+            u32 nmax = 0;
+#pragma unroll
+            for (int q = 0; q < WPL; q++) { if (gn[q] == MI_BIG) gn[q] = 0; else if (pend[q]) { pend[q] = false; nmax = max(nmax, gn[q]); } else gn[q] = 0; }
+            // (lanes of an oversized / ambiguous group keep pend = true and fall through to the uniform table below)
+            u32 wmax = nmax;
+            wmax = max(wmax, dpp_mov<0x111, 0xF>(0, wmax)); wmax = max(wmax, dpp_mov<0x112, 0xF>(0, wmax)); wmax = max(wmax, dpp_mov<0x114, 0xF>(0, wmax)); wmax = max(wmax, dpp_mov<0x118, 0xF>(0, wmax));
+            wmax = max(wmax, dpp_mov<0x142, 0xA>(0, wmax)); wmax = max(wmax, dpp_mov<0x143, 0xC>(0, wmax));
+            wmax = (u32)__builtin_amdgcn_readlane((int)wmax, 63);
+            for (u32 x = 0; x < wmax; x += 8) {                                  // 8 independent loads per window and step
+                u64 r[WPL][8];
+#pragma unroll
+                for (int q = 0; q < WPL; q++)
+#pragma unroll
+                    for (int u = 0; u < 8; u++) r[q][u] = A.krec[goff[q] + (x + u < gn[q] ? x + u : 0u)];
+#pragma unroll
+                for (int q = 0; q < WPL; q++)
+#pragma unroll
+                    for (int u = 7; u >= 0; u--) if (x + u < gn[q] && (u32)(r[q][u] >> SLOT_TAG_SHIFT) == tg[q]) sl[q] = r[q][u];
+            }
+        }
+        // 1c. uniform table (everything when there is no minimiser index; otherwise only windows of oversized groups)
         for (;;) {
             bool any = false;
 #pragma unroll
@@ -972,24 +1139,33 @@ __global__ void k_recip_cond(u64 N, const u64* __restrict__ right, const u64* __
     }
 }
 __device__ __forceinline__ u32 flip_type(u32 t) { return t == 0 ? 3u : (t == 3 ? 0u : t); }   // utils.cpp:212
-__device__ __forceinline__ void emit_edge(EdgeCand* cand, u64 cap, u64* counters, const u64* reads, int S, u64 u, u64 v, u32 delta, u32 type) {
-    if (u == v) return;                                                                    // economyGraph.cpp:815
+__device__ __forceinline__ EdgeCand make_edge(const u64* reads, int S, u64 u, u64 v, u32 delta, u32 type) {
     EdgeCand e;
     if (u < v) { e.from = (u32)u; e.to = (u32)v; e.len = delta & 0xFFFFFu; e.type = type; }
     else {                                                                                  // the twin lives in the smaller id's list
         int Lu = (int)(reads[u * S + S - 1] & 0xFFFF), Lv = (int)(reads[v * S + S - 1] & 0xFFFF);
         e.from = (u32)v; e.to = (u32)u; e.len = (u32)(Lu - (Lv - (int)delta)) & 0xFFFFFu; e.type = flip_type(type);   // economyGraph.cpp:821
     }
-    u64 p = atomicAdd(&counters[0], 1ull);
-    if (p < cap) cand[p] = e;
+    return e;
 }
 __global__ void k_recip_emit(u64 N, const u64* __restrict__ reads, int S, const u64* __restrict__ right, const u64* __restrict__ left,
                              const uint8_t* __restrict__ status, EdgeCand* cand, u64 cap, u64* counters, u64 elo, u64 ehi) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x + elo;
-    if (i >= ehi || i > N || status[i] != 4) return;
-    u64 l = left[i], r = right[i]; u64 lid = l & ID_MASK, rid = r & ID_MASK;
-    if (!(lid < i && status[lid] == 4)) emit_edge(cand, cap, counters, reads, S, i, lid, (u32)(l >> 42), ((l >> 40) & 3) == 0 ? 0u : 1u);   // :462-467
-    if (!(rid < i && status[rid] == 4)) emit_edge(cand, cap, counters, reads, S, i, rid, (u32)(r >> 42), ((r >> 40) & 3) == 0 ? 3u : 2u);   // :468-473
+    const bool act = i < ehi && i <= N && status[i] == 4;
+    u64 l = 0, r = 0, lid = 0, rid = 0; bool eL = false, eR = false;
+    if (act) {
+        l = left[i]; r = right[i]; lid = l & ID_MASK; rid = r & ID_MASK;
+        eL = lid != i && !(lid < i && status[lid] == 4);                                    // :462-467 (and u != v, :815)
+        eR = rid != i && !(rid < i && status[rid] == 4);                                    // :468-473
+    }
+    // one atomic per wave: positions by ballot prefix
+    const u64 bL = __ballot(eL), bR = __ballot(eR); const u32 nL = (u32)__popcll(bL), nR = (u32)__popcll(bR);
+    if (nL + nR == 0) return;
+    u64 base = 0; if (lane_id() == 0) base = atomicAdd(&counters[0], (u64)(nL + nR));
+    base = __shfl(base, 0);
+    const u64 lt = (1ull << lane_id()) - 1ull;
+    if (eL) { const u64 p = base + __popcll(bL & lt); if (p < cap) cand[p] = make_edge(reads, S, i, lid, (u32)(l >> 42), ((l >> 40) & 3) == 0 ? 0u : 1u); }
+    if (eR) { const u64 p = base + nL + __popcll(bR & lt); if (p < cap) cand[p] = make_edge(reads, S, i, rid, (u32)(r >> 42), ((r >> 40) & 3) == 0 ? 3u : 2u); }
 }
 
 // reduce-phase support: the host replay needs the lists of unresolved reads and of their neighbours
@@ -1114,6 +1290,9 @@ int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t
     WS(where, u32, WS_WHERE, std::max<u64>(1, 4 * N));
     WS(big, u64, WS_BIG, (u64)big_cap * 3);
     WS(csr_ws, u32, WS_CSR, std::max<u64>(1, 4 * N)); d->csr = csr_ws;
+    const bool wantMI = !getenv("SAGE2OV_NO_MINIMIZER_INDEX");
+    u32* slot_mh = nullptr;
+    if (wantMI) { WS(smh, u32, WS_SLOTMH, d->T); slot_mh = smh; }
     HIPCHK(hipEventRecord(d->ev[0], d->stream));
     *rebuilds = 0;
     for (int attempt = 0;; attempt++) {
@@ -1132,7 +1311,7 @@ int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t
         hipLaunchKernelGGL(k_index_count, dim3(gE), dim3(256), 0, d->stream, d->reads, N, d->S, d->h, d->seed, d->slots, d->T, cnt, where, dbgk);
         if (dbgk) { HIPCHK(hipStreamSynchronize(d->stream)); d->dbg_keys.resize(16 * N); HIPCHK(hipMemcpy(d->dbg_keys.data(), dbgk, 16 * N * sizeof(u64), hipMemcpyDeviceToHost)); hipFree(dbgk); }
         hipLaunchKernelGGL(k_index_alloc, dim3(grid_for(d->T, ALLOC_ITEMS)), dim3(256), 0, d->stream, d->slots, d->T, cnt, d->d_counters + 8, big, big_cap);
-        hipLaunchKernelGGL(k_index_fill, dim3(gE), dim3(256), 0, d->stream, N, d->slots, cnt, where, d->csr);
+        hipLaunchKernelGGL(k_index_fill, dim3(gE), dim3(256), 0, d->stream, d->reads, N, d->S, d->h, (u32)d->seed, d->slots, cnt, where, d->csr, slot_mh);
         hipLaunchKernelGGL(k_index_sort, dim3(grid_for(d->T, 256)), dim3(256), 0, d->stream, d->slots, d->T, d->csr);
         u64 c[5];
         HIPCHK(hipMemcpyAsync(c, d->d_counters + 8, sizeof c, hipMemcpyDeviceToHost, d->stream));
@@ -1146,6 +1325,23 @@ int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t
         if (c[3] == 0) { d->n_csr = c[0]; d->n_keys = c[1]; d->n_long = c[2]; break; }
         if (attempt >= 8) { err = "index build: tag collisions in long buckets persist after 8 reseeds"; return SAGE2OV_ERR_INTERNAL; }
         d->seed = d->seed * 0x9E3779B97F4A7C15ull + 12345; (*rebuilds)++;
+    }
+    // ---- stage B: minimiser groups over the distinct-key records
+    d->mi1 = nullptr; d->krec = nullptr; d->TL = 0;
+    if (wantMI && d->n_keys > 0) {
+        u64 TL = 1024; while (TL < d->T / 4) TL <<= 1;                       // >= 2N group slots
+        WS(mi1, u64, WS_MI1, TL); WS(mcnt, u32, WS_MICNT, TL); WS(mcur, u32, WS_MICUR, TL); WS(krec, u64, WS_KREC, d->n_keys + 1);
+        HIPCHK(hipMemsetAsync(mi1, 0, TL * sizeof(u64), d->stream)); HIPCHK(hipMemsetAsync(mcnt, 0, TL * sizeof(u32), d->stream));
+        HIPCHK(hipMemsetAsync(mcur, 0, TL * sizeof(u32), d->stream)); HIPCHK(hipMemsetAsync(d->d_counters + 8 + 5, 0, 2 * sizeof(u64), d->stream));
+        hipLaunchKernelGGL(k_mi_count, dim3(grid_for(d->T, 256)), dim3(256), 0, d->stream, d->slots, d->T, slot_mh, mi1, TL, mcnt);
+        hipLaunchKernelGGL(k_mi_alloc, dim3(grid_for(TL, ALLOC_ITEMS)), dim3(256), 0, d->stream, mi1, TL, mcnt, d->d_counters + 8);
+        hipLaunchKernelGGL(k_mi_fill, dim3(grid_for(d->T, 256)), dim3(256), 0, d->stream, d->slots, d->T, slot_mh, mi1, TL, mcur, krec);
+        hipLaunchKernelGGL(k_mi_check, dim3(grid_for(TL, 256)), dim3(256), 0, d->stream, mi1, TL, krec);
+        u64 mc[2];
+        HIPCHK(hipMemcpyAsync(mc, d->d_counters + 8 + 5, sizeof mc, hipMemcpyDeviceToHost, d->stream));
+        HIPCHK(hipStreamSynchronize(d->stream));
+        d->n_groups = mc[1];
+        if (mc[1] * 10 <= TL * 7) { d->mi1 = mi1; d->krec = krec; d->TL = TL; }      // else: too crowded, the fast kernel uses the uniform table
     }
     HIPCHK(hipEventRecord(d->ev[1], d->stream));
     HIPCHK(hipStreamSynchronize(d->stream));
@@ -1206,6 +1402,7 @@ static ProbeArgs base_args(Device* d) {
     ProbeArgs A; memset(&A, 0, sizeof A);
     A.reads = d->reads; A.N = d->N; A.S = d->S; A.k = d->k; A.h = d->h; A.slots = d->slots; A.T = d->T; A.csr = d->csr; A.seed = d->seed;
     A.right = d->right; A.left = d->left; A.conn = d->conn; A.cflag = d->cflag; A.status = d->status; A.counters = d->d_counters;
+    A.mi1 = d->mi1; A.TL = d->TL; A.krec = d->krec;
     return A;
 }
 
