@@ -239,7 +239,7 @@ def main():
         tj = os.path.join(ROOT, "profiles", "probe_traffic.json")
         if os.path.exists(tj):
             try:
-                traffic = json.load(open(tj)).get(f"{args.reads}x{args.read_len}_k{args.k}")
+                traffic = json.load(open(tj)).get(f"{args.reads}x{args.read_len}_k{args.k}", {}).get("bytes_per_launch")
             except Exception:
                 traffic = None
         res = {
@@ -254,7 +254,7 @@ def main():
                        "timed_region": "index build + initial pass + reduce + sort/convert; reads resident in HBM"},
             "phases_ms": {kph: v / args.steps for kph, v in phase.items()},
             "reads_per_s": st.unique_reads / (elapsed / args.steps),
-            "roofline": {"bound": "hbm", "kernel": "k_probe", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "k_probe_fast", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": a_probe * share,
                          "whole_path_achieved": a_total / (elapsed / args.steps) / 1e9, "whole_path_frac": a_total / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
