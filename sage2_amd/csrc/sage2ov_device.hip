@@ -355,9 +355,10 @@ __global__ void k_index_purity(const u64* __restrict__ reads, int S, int h, cons
     else if (lane_id() == 0) atomicAdd(&counters[4], 1ull);
 }
 // ---- stage B of the index build: group the distinct-key records of the uniform table by minimiser
+// bounded: a full group table (more distinct minimisers than expected) must never spin forever; ~0 = gave up
 __device__ __forceinline__ u64 mi_find_or_claim(u64* mi1, u64 TL, u32 mh, bool claim) {
     const u64 mt = minim_tag(mh); u64 idx = __umulhi(mh, (u32)TL);
-    for (;;) {
+    for (u32 step = 0; step < 2048u; step++) {
         u64 v = __hip_atomic_load(&mi1[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (v == 0) {
             if (!claim) return ~0ull;
@@ -366,11 +367,13 @@ __device__ __forceinline__ u64 mi_find_or_claim(u64* mi1, u64 TL, u32 mh, bool c
         } else if ((v >> SLOT_TAG_SHIFT) == mt) return idx;
         if (++idx == TL) idx = 0;
     }
+    return ~0ull;
 }
-__global__ void k_mi_count(const u64* __restrict__ slots, u64 T, const u32* __restrict__ slot_mh, u64* mi1, u64 TL, u32* mcnt) {
+__global__ void k_mi_count(const u64* __restrict__ slots, u64 T, const u32* __restrict__ slot_mh, u64* mi1, u64 TL, u32* mcnt, u64* counters) {
     const u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x; if (idx >= T) return;
     const u64 s = slots[idx]; if (s == 0) return;
     const u64 g = mi_find_or_claim(mi1, TL, slot_mh[idx], true);
+    if (g == ~0ull) { atomicAdd(&counters[7], 1ull); return; }         // group table too crowded: the host drops the minimiser index
     atomicAdd(&mcnt[g], 1u);
 }
 __global__ __launch_bounds__(256) void k_mi_alloc(u64* mi1, u64 TL, const u32* __restrict__ mcnt, u64* counters) {   // counters[5]: records placed, [6]: groups
@@ -397,6 +400,7 @@ __global__ void k_mi_fill(const u64* __restrict__ slots, u64 T, const u32* __res
     const u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x; if (idx >= T) return;
     const u64 s = slots[idx]; if (s == 0) return;
     const u64 g = mi_find_or_claim(mi1, TL, slot_mh[idx], false);
+    if (g == ~0ull) return;
     const u64 v = mi1[g];
     if (((v >> 32) & 255u) == MI_BIG) return;                       // oversized group: never scanned
     const u32 pos = atomicAdd(&mcur[g], 1u);
@@ -1290,7 +1294,7 @@ int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t
     WS(where, u32, WS_WHERE, std::max<u64>(1, 4 * N));
     WS(big, u64, WS_BIG, (u64)big_cap * 3);
     WS(csr_ws, u32, WS_CSR, std::max<u64>(1, 4 * N)); d->csr = csr_ws;
-    const bool wantMI = !getenv("SAGE2OV_NO_MINIMIZER_INDEX");
+    const bool wantMI = !getenv("SAGE2OV_NO_MINIMIZER_INDEX") && (d->h - std::min(d->h, 16) + 1) >= 8;
     u32* slot_mh = nullptr;
     if (wantMI) { WS(smh, u32, WS_SLOTMH, d->T); slot_mh = smh; }
     HIPCHK(hipEventRecord(d->ev[0], d->stream));
@@ -1332,16 +1336,16 @@ int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t
         u64 TL = 1024; while (TL < d->T / 4) TL <<= 1;                       // >= 2N group slots
         WS(mi1, u64, WS_MI1, TL); WS(mcnt, u32, WS_MICNT, TL); WS(mcur, u32, WS_MICUR, TL); WS(krec, u64, WS_KREC, d->n_keys + 1);
         HIPCHK(hipMemsetAsync(mi1, 0, TL * sizeof(u64), d->stream)); HIPCHK(hipMemsetAsync(mcnt, 0, TL * sizeof(u32), d->stream));
-        HIPCHK(hipMemsetAsync(mcur, 0, TL * sizeof(u32), d->stream)); HIPCHK(hipMemsetAsync(d->d_counters + 8 + 5, 0, 2 * sizeof(u64), d->stream));
-        hipLaunchKernelGGL(k_mi_count, dim3(grid_for(d->T, 256)), dim3(256), 0, d->stream, d->slots, d->T, slot_mh, mi1, TL, mcnt);
+        HIPCHK(hipMemsetAsync(mcur, 0, TL * sizeof(u32), d->stream)); HIPCHK(hipMemsetAsync(d->d_counters + 8 + 5, 0, 3 * sizeof(u64), d->stream));
+        hipLaunchKernelGGL(k_mi_count, dim3(grid_for(d->T, 256)), dim3(256), 0, d->stream, d->slots, d->T, slot_mh, mi1, TL, mcnt, d->d_counters + 8);
         hipLaunchKernelGGL(k_mi_alloc, dim3(grid_for(TL, ALLOC_ITEMS)), dim3(256), 0, d->stream, mi1, TL, mcnt, d->d_counters + 8);
         hipLaunchKernelGGL(k_mi_fill, dim3(grid_for(d->T, 256)), dim3(256), 0, d->stream, d->slots, d->T, slot_mh, mi1, TL, mcur, krec);
         hipLaunchKernelGGL(k_mi_check, dim3(grid_for(TL, 256)), dim3(256), 0, d->stream, mi1, TL, krec);
-        u64 mc[2];
+        u64 mc[3];
         HIPCHK(hipMemcpyAsync(mc, d->d_counters + 8 + 5, sizeof mc, hipMemcpyDeviceToHost, d->stream));
         HIPCHK(hipStreamSynchronize(d->stream));
         d->n_groups = mc[1];
-        if (mc[1] * 10 <= TL * 7) { d->mi1 = mi1; d->krec = krec; d->TL = TL; }      // else: too crowded, the fast kernel uses the uniform table
+        if (mc[2] == 0 && mc[1] * 10 <= TL * 7) { d->mi1 = mi1; d->krec = krec; d->TL = TL; }   // else: too crowded, the fast kernel uses the uniform table
     }
     HIPCHK(hipEventRecord(d->ev[1], d->stream));
     HIPCHK(hipStreamSynchronize(d->stream));

@@ -254,3 +254,47 @@ def test_cli_steps_1_to_3_write_reference_files(tmp_path):
     want = fx.golden_graph3("g6_k70_150").split(b"\n", 3)
     assert got[3] == want[3]          # edge records identical (the 3 header lines need the FASTA totals, which P.reads lacks)
     assert os.path.exists(os.path.join(out, "t.log"))
+
+
+@pytest.mark.parametrize("pd,k", [
+    (dict(seed=31, genome_len=30000, n_reads=9000, read_len=250, err_ppm=300), 40),        # 16-dword compare, 4 windows per lane
+    (dict(seed=32, genome_len=30000, n_reads=9000, read_len=200, read_len_min=120, err_ppm=500), 31),   # mixed lengths in the long layout
+    (dict(seed=33, genome_len=24000, n_reads=8000, read_len=150, err_ppm=0), 21),          # 130 windows: 4 windows per lane, 10-dword compare
+    (dict(seed=34, genome_len=40000, n_reads=6000, read_len=300, err_ppm=300), 55),        # 16-word slots: sequential kernel only
+    (dict(seed=35, genome_len=12000, n_reads=9000, read_len=60, err_ppm=0), 15),           # short reads, h < 16 (minimiser width = h)
+])
+def test_other_kernel_instantiations_match_oracle(pd, k):
+    """every template instantiation of the probe kernels (slot width, compare width, windows per lane) and the
+    sequential-only path, against the oracle"""
+    bases, off = fx.make_reads(pd)
+    m = dict(k=k)
+    g, o = run_gpu(m, bases, off), run_oracle(m, bases, off)
+    gr, gl, gs, gc = g.overlap_export_initial(); orr, orl, ors, orc = o.export_initial()
+    assert np.array_equal(gc, orc) and np.array_equal(gr[1:], orr[1:]) and np.array_equal(gl[1:], orl[1:])
+    e, oe = g.edges(), o.export_edges()
+    assert len(e) == len(oe) and np.array_equal(e["from"], oe[:, 0]) and np.array_equal(e["to"], oe[:, 1])
+    assert np.array_equal(e["type"], oe[:, 2]) and np.array_equal(e["length"], oe[:, 3]) and np.array_equal(e["length_twin"], oe[:, 4])
+    g.close(); o.close()
+
+
+def test_fastq_gz_input_and_bad_reads(tmp_path):
+    """FASTQ, gzip, lower case, reads with N and reads not longer than k (readLoader.cpp:145-158, utils.cpp:144)"""
+    import gzip
+    m = fx.golden("g1_clean100_k21")
+    bases, off = fx.make_reads(m["synth"])
+    seqs = [bytes(bases[int(off[i]):int(off[i + 1])]).decode() for i in range(len(off) - 1)]
+    fq = str(tmp_path / "x.fastq.gz")
+    with gzip.open(fq, "wt") as f:
+        for i, sq in enumerate(seqs):
+            if i % 1000 == 0:
+                f.write(f"@bad{i}\nACGTNNACGT{sq[:50]}\n+\n{'I' * 60}\n")            # contains N: dropped
+                f.write(f"@short{i}\n{sq[:21]}\n+\n{'I' * 21}\n")                    # length == k: dropped
+            s_out = sq.lower() if i % 7 == 0 else sq
+            f.write(f"@r{i}\n{s_out}\n+\n{'I' * len(sq)}\n")
+    c = s2.Context(m["k"]); c.reads_add_file(fq); c.reads_organize(); c.run_steps23()
+    st = c.reads_stats()
+    assert st.good_reads == len(seqs) and st.total_reads == len(seqs) + 2 * ((len(seqs) + 999) // 1000)
+    rp, gp = str(tmp_path / "t.reads"), str(tmp_path / "t.graph3")
+    c.reads_save(rp); c.graph_save(gp)
+    assert fx.md5_file(rp) == m["reads_md5"] and open(gp, "rb").read() == fx.golden_graph3("g1_clean100_k21")
+    c.close()
