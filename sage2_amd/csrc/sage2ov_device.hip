@@ -317,7 +317,9 @@ __global__ __launch_bounds__(256) void k_index_alloc(u64* slots, u64 T, const u3
         }
     }
 }
-__global__ void k_index_fill(const u64* __restrict__ reads, u64 N, int S, int h, u32 seed, u64* slots, u32* cnt, const u32* __restrict__ where, u32* csr, u32* slot_mh) {
+__device__ __forceinline__ u64 mi_find_or_claim(u64* mi1, u64 TL, u32 mh, bool claim);
+__global__ void k_index_fill(const u64* __restrict__ reads, u64 N, int S, int h, u32 seed, u64* slots, u32* cnt, const u32* __restrict__ where, u32* csr, u32* slot_mh,
+                             u64* mi1, u64 TL, u32* mcnt, u64* micounters) {
     u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     const u64 stride = (u64)gridDim.x * blockDim.x;
     for (; e < 4 * N; e += stride) {
@@ -327,10 +329,12 @@ __global__ void k_index_fill(const u64* __restrict__ reads, u64 N, int S, int h,
         bool designated;
         if (c7 == 0) { slots[idx] = (s & (~0ull << SLOT_TAG_SHIFT)) | (1ull << SLOT_CNT_SHIFT) | entry; designated = true; }   // the only entry: inline
         else { u32 pos = atomicSub(&cnt[idx], 1u) - 1u; csr[(s & SLOT_PAY_MASK) + pos] = entry; designated = pos == 0; }
-        if (slot_mh && designated) {                                   // one entry per bucket: minimiser of the bucket's key (stage B)
+        if (slot_mh && designated) {                                   // one entry per bucket: claim / count the minimiser group of its key (stage B)
             u64 hi, lo; entry_key(reads, S, h, (e >> 2) + 1, (int)(e & 3), hi, lo);
             u32 k0, k1, k2, k3; key_left_align(hi, lo, h, k0, k1, k2, k3);
-            slot_mh[idx] = minim_hash(key_min_hash(k0, k1, k2, k3, h), seed);
+            const u64 g = mi_find_or_claim(mi1, TL, minim_hash(key_min_hash(k0, k1, k2, k3, h), seed), true);
+            if (g == ~0ull) atomicAdd(&micounters[7], 1ull); else atomicAdd(&mcnt[g], 1u);
+            slot_mh[idx] = (u32)g;                                     // group slot of this bucket (0xFFFFFFFF: none)
         }
     }
 }
@@ -369,13 +373,6 @@ __device__ __forceinline__ u64 mi_find_or_claim(u64* mi1, u64 TL, u32 mh, bool c
     }
     return ~0ull;
 }
-__global__ void k_mi_count(const u64* __restrict__ slots, u64 T, const u32* __restrict__ slot_mh, u64* mi1, u64 TL, u32* mcnt, u64* counters) {
-    const u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x; if (idx >= T) return;
-    const u64 s = slots[idx]; if (s == 0) return;
-    const u64 g = mi_find_or_claim(mi1, TL, slot_mh[idx], true);
-    if (g == ~0ull) { atomicAdd(&counters[7], 1ull); return; }         // group table too crowded: the host drops the minimiser index
-    atomicAdd(&mcnt[g], 1u);
-}
 __global__ __launch_bounds__(256) void k_mi_alloc(u64* mi1, u64 TL, const u32* __restrict__ mcnt, u64* counters) {   // counters[5]: records placed, [6]: groups
     __shared__ u32 sh[4]; __shared__ u64 shBase;
     const u64 base0 = (u64)blockIdx.x * ALLOC_ITEMS;
@@ -396,25 +393,16 @@ __global__ __launch_bounds__(256) void k_mi_alloc(u64* mi1, u64 TL, const u32* _
         }
     }
 }
-__global__ void k_mi_fill(const u64* __restrict__ slots, u64 T, const u32* __restrict__ slot_mh, u64* mi1, u64 TL, u32* mcur, u64* krec) {
+__global__ void k_mi_fill(const u64* __restrict__ slots, u64 T, const u32* __restrict__ slot_mh, const u64* __restrict__ mi1, u32* mcur, u64* krec) {
     const u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x; if (idx >= T) return;
     const u64 s = slots[idx]; if (s == 0) return;
-    const u64 g = mi_find_or_claim(mi1, TL, slot_mh[idx], false);
-    if (g == ~0ull) return;
+    const u32 g = slot_mh[idx];
+    if (g == 0xFFFFFFFFu) return;
     const u64 v = mi1[g];
     if (((v >> 32) & 255u) == MI_BIG) return;                       // oversized group: never scanned
     const u32 pos = atomicAdd(&mcur[g], 1u);
     krec[(u32)v + pos] = s;
 }
-// a group in which two records share a tag cannot be scanned unambiguously: send its windows to the uniform table
-__global__ void k_mi_check(u64* mi1, u64 TL, const u64* __restrict__ krec) {
-    const u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x; if (g >= TL) return;
-    const u64 v = mi1[g]; const u32 n = (u32)(v >> 32) & 255u; if (v == 0 || n < 2 || n == MI_BIG) return;
-    const u64* r = krec + (u32)v; bool dup = false;
-    for (u32 a = 1; a < n && !dup; a++) for (u32 b = 0; b < a; b++) if ((r[a] >> SLOT_TAG_SHIFT) == (r[b] >> SLOT_TAG_SHIFT)) { dup = true; break; }
-    if (dup) mi1[g] = (v & ~(0xFFull << 32)) | ((u64)MI_BIG << 32);
-}
-
 __global__ void k_lookup(const u64* __restrict__ slots, u64 T, const u32* __restrict__ csr, u64 seed, int h, u64 hi, u64 lo, u64* out, u32 cap) {
     u64 s = table_find(slots, T, hash_key(hi, lo, h, seed));
     u32 c7 = (u32)(s >> SLOT_CNT_SHIFT) & 127u;
@@ -894,6 +882,9 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_probe_fast(ProbeArgs A) {
             wmax = max(wmax, dpp_mov<0x111, 0xF>(0, wmax)); wmax = max(wmax, dpp_mov<0x112, 0xF>(0, wmax)); wmax = max(wmax, dpp_mov<0x114, 0xF>(0, wmax)); wmax = max(wmax, dpp_mov<0x118, 0xF>(0, wmax));
             wmax = max(wmax, dpp_mov<0x142, 0xA>(0, wmax)); wmax = max(wmax, dpp_mov<0x143, 0xC>(0, wmax));
             wmax = (u32)__builtin_amdgcn_readlane((int)wmax, 63);
+            u32 nmatch[WPL];
+#pragma unroll
+            for (int q = 0; q < WPL; q++) nmatch[q] = 0;
             for (u32 x = 0; x < wmax; x += 8) {                                  // 8 independent loads per window and step
                 u64 r[WPL][8];
 #pragma unroll
@@ -903,8 +894,13 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_probe_fast(ProbeArgs A) {
 #pragma unroll
                 for (int q = 0; q < WPL; q++)
 #pragma unroll
-                    for (int u = 7; u >= 0; u--) if (x + u < gn[q] && (u32)(r[q][u] >> SLOT_TAG_SHIFT) == tg[q]) sl[q] = r[q][u];
+                    for (int u = 7; u >= 0; u--) if (x + u < gn[q] && (u32)(r[q][u] >> SLOT_TAG_SHIFT) == tg[q]) { sl[q] = r[q][u]; nmatch[q]++; }
             }
+            // two records of one group with the same tag (two keys, ~2^-24 per pair): the scan cannot tell them apart
+            bool amb = false;
+#pragma unroll
+            for (int q = 0; q < WPL; q++) amb |= nmatch[q] > 1;
+            if (__any(amb)) slowpath = true;
         }
         // 1c. uniform table (everything when there is no minimiser index; otherwise only windows of oversized groups)
         for (;;) {
@@ -1295,8 +1291,12 @@ int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t
     WS(big, u64, WS_BIG, (u64)big_cap * 3);
     WS(csr_ws, u32, WS_CSR, std::max<u64>(1, 4 * N)); d->csr = csr_ws;
     const bool wantMI = !getenv("SAGE2OV_NO_MINIMIZER_INDEX") && (d->h - std::min(d->h, 16) + 1) >= 8;
-    u32* slot_mh = nullptr;
-    if (wantMI) { WS(smh, u32, WS_SLOTMH, d->T); slot_mh = smh; }
+    u32* slot_mh = nullptr; u64* mi1 = nullptr; u32 *mcnt = nullptr, *mcur = nullptr; u64 TL = 0;
+    if (wantMI) {
+        TL = 1024; while (TL < d->T / 4) TL <<= 1;                           // >= 2N group slots
+        WS(smh, u32, WS_SLOTMH, d->T); slot_mh = smh;
+        WS(m1, u64, WS_MI1, TL); mi1 = m1; WS(mc_, u32, WS_MICNT, TL); mcnt = mc_; WS(mu_, u32, WS_MICUR, TL); mcur = mu_;
+    }
     HIPCHK(hipEventRecord(d->ev[0], d->stream));
     *rebuilds = 0;
     for (int attempt = 0;; attempt++) {
@@ -1308,14 +1308,15 @@ int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t
         HIPCHK(hipMemsetAsync(d->slots, 0, d->T * sizeof(u64), d->stream));
         HIPCHK(hipMemsetAsync(cnt, 0, d->T * sizeof(u32), d->stream));
         }
-        HIPCHK(hipMemsetAsync(d->d_counters + 8, 0, 5 * sizeof(u64), d->stream));
+        HIPCHK(hipMemsetAsync(d->d_counters + 8, 0, 8 * sizeof(u64), d->stream));
+        if (wantMI) { HIPCHK(hipMemsetAsync(mi1, 0, TL * sizeof(u64), d->stream)); HIPCHK(hipMemsetAsync(mcnt, 0, TL * sizeof(u32), d->stream)); HIPCHK(hipMemsetAsync(mcur, 0, TL * sizeof(u32), d->stream)); }
         const unsigned gE = (unsigned)std::min<u64>(grid_for(4 * N, 256), 256 * 64);
         u64* dbgk = nullptr;
         if (getenv("SAGE2OV_DBG_WHERE")) HIPCHK(hipMalloc(&dbgk, 16 * N * sizeof(u64)));
         hipLaunchKernelGGL(k_index_count, dim3(gE), dim3(256), 0, d->stream, d->reads, N, d->S, d->h, d->seed, d->slots, d->T, cnt, where, dbgk);
         if (dbgk) { HIPCHK(hipStreamSynchronize(d->stream)); d->dbg_keys.resize(16 * N); HIPCHK(hipMemcpy(d->dbg_keys.data(), dbgk, 16 * N * sizeof(u64), hipMemcpyDeviceToHost)); hipFree(dbgk); }
         hipLaunchKernelGGL(k_index_alloc, dim3(grid_for(d->T, ALLOC_ITEMS)), dim3(256), 0, d->stream, d->slots, d->T, cnt, d->d_counters + 8, big, big_cap);
-        hipLaunchKernelGGL(k_index_fill, dim3(gE), dim3(256), 0, d->stream, d->reads, N, d->S, d->h, (u32)d->seed, d->slots, cnt, where, d->csr, slot_mh);
+        hipLaunchKernelGGL(k_index_fill, dim3(gE), dim3(256), 0, d->stream, d->reads, N, d->S, d->h, (u32)d->seed, d->slots, cnt, where, d->csr, slot_mh, mi1, TL, mcnt, d->d_counters + 8);
         hipLaunchKernelGGL(k_index_sort, dim3(grid_for(d->T, 256)), dim3(256), 0, d->stream, d->slots, d->T, d->csr);
         u64 c[5];
         HIPCHK(hipMemcpyAsync(c, d->d_counters + 8, sizeof c, hipMemcpyDeviceToHost, d->stream));
@@ -1333,14 +1334,9 @@ int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t
     // ---- stage B: minimiser groups over the distinct-key records
     d->mi1 = nullptr; d->krec = nullptr; d->TL = 0;
     if (wantMI && d->n_keys > 0) {
-        u64 TL = 1024; while (TL < d->T / 4) TL <<= 1;                       // >= 2N group slots
-        WS(mi1, u64, WS_MI1, TL); WS(mcnt, u32, WS_MICNT, TL); WS(mcur, u32, WS_MICUR, TL); WS(krec, u64, WS_KREC, d->n_keys + 1);
-        HIPCHK(hipMemsetAsync(mi1, 0, TL * sizeof(u64), d->stream)); HIPCHK(hipMemsetAsync(mcnt, 0, TL * sizeof(u32), d->stream));
-        HIPCHK(hipMemsetAsync(mcur, 0, TL * sizeof(u32), d->stream)); HIPCHK(hipMemsetAsync(d->d_counters + 8 + 5, 0, 3 * sizeof(u64), d->stream));
-        hipLaunchKernelGGL(k_mi_count, dim3(grid_for(d->T, 256)), dim3(256), 0, d->stream, d->slots, d->T, slot_mh, mi1, TL, mcnt, d->d_counters + 8);
+        WS(krec, u64, WS_KREC, d->n_keys + 1);
         hipLaunchKernelGGL(k_mi_alloc, dim3(grid_for(TL, ALLOC_ITEMS)), dim3(256), 0, d->stream, mi1, TL, mcnt, d->d_counters + 8);
-        hipLaunchKernelGGL(k_mi_fill, dim3(grid_for(d->T, 256)), dim3(256), 0, d->stream, d->slots, d->T, slot_mh, mi1, TL, mcur, krec);
-        hipLaunchKernelGGL(k_mi_check, dim3(grid_for(TL, 256)), dim3(256), 0, d->stream, mi1, TL, krec);
+        hipLaunchKernelGGL(k_mi_fill, dim3(grid_for(d->T, 256)), dim3(256), 0, d->stream, d->slots, d->T, slot_mh, mi1, mcur, krec);
         u64 mc[3];
         HIPCHK(hipMemcpyAsync(mc, d->d_counters + 8 + 5, sizeof mc, hipMemcpyDeviceToHost, d->stream));
         HIPCHK(hipStreamSynchronize(d->stream));
