@@ -160,8 +160,13 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        backend = os.environ.get("SAGE2OV_BENCH_BACKEND", "nccl")      # "gloo": rehearsal of the N>1 path on a box with fewer GPUs than ranks
+        if backend != "nccl":
+            local = local % torch.cuda.device_count()
+            dist.init_process_group(backend)
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     assert torch.cuda.is_available(), "bench.py needs a GPU: the hot path has no CPU fallback"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
@@ -188,7 +193,10 @@ def main():
             tw = torch.from_numpy(words.view(np.int64)).to(dev)
         else:
             tw = torch.empty((n_u + 1) * wpr, dtype=torch.int64, device=dev)
-        dist.broadcast(tw, 0)
+        if dist.get_backend() == "gloo":
+            th = tw.cpu(); dist.broadcast(th, 0); tw = th
+        else:
+            dist.broadcast(tw, 0)
         if rank != 0:
             ctx.reads_import_words(tw.cpu().numpy().view(np.uint64), n_u, wpr, mlen, np.ones(n_u + 1, dtype=np.uint16), good, bp)
         del tw
@@ -226,9 +234,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ost = ctx.overlap_stats()
+    import zlib
+    edges_crc = zlib.crc32(ctx.edges().tobytes())                   # canonical edge list (from, to, type, length): same at every N
+    if world > 1:
+        t = torch.tensor([edges_crc], dtype=torch.int64, device=dev)
+        tmin, tmax = t.clone(), t.clone()
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        assert int(tmin.item()) == int(tmax.item()) == edges_crc, "ranks disagree on the final edge list"
     ms_per_step = 1e3 * elapsed / args.steps
     value = ost.verified_overlaps / (elapsed / args.steps)
 
+    cfg_name = {10_000_000: "BASELINE.json configs[1]", 50_000_000: "BASELINE.json configs[2]/[3]"}.get(args.reads, "scaled-down BASELINE.json configs[1]") \
+        if (args.read_len, args.k) == (150, 40) else "custom"
     if rank == 0:
         a_total, a_probe = algorithmic_bytes(st.unique_reads, ost.verified_overlaps, ost.edges, args.read_len, args.k)
         lo, hi = ctx.shard_range()
@@ -248,8 +265,8 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"{args.reads} x {args.read_len} bp synthetic paired-end reads, k={args.k}, {args.genome} bp uniform random genome, "
-                                   f"seed {args.seed}, err {args.err_ppm} ppm (BASELINE.json configs[1])",
-                       "unique_reads": st.unique_reads, "verified_overlaps": ost.verified_overlaps, "edges": ost.edges,
+                                   f"seed {args.seed}, err {args.err_ppm} ppm ({cfg_name})",
+                       "unique_reads": st.unique_reads, "verified_overlaps": ost.verified_overlaps, "edges": ost.edges, "edges_crc32": edges_crc,
                        "unresolved_reads": ost.left_to_explore, "partition": f"read-id range x{world}" if world > 1 else "single GPU",
                        "timed_region": "index build + initial pass + reduce + sort/convert; reads resident in HBM"},
             "phases_ms": {kph: v / args.steps for kph, v in phase.items()},

@@ -19,9 +19,25 @@ EDGE_BYTES = 16
 
 
 def _sync(t: torch.Tensor):
-    """collectives run on torch's stream, the library on its own: fence before handing buffers over"""
+    """collectives (and torch's own fills/copies) run on torch's stream, the library on its own:
+    fence before handing buffers over, in either direction"""
     if t.is_cuda:
         torch.cuda.current_stream(t.device).synchronize()
+
+
+def _staged(group=None):
+    """gloo has no all-gather for device tensors: a rehearsal of the multi-rank path on a box without RCCL peers
+    (e.g. 2 ranks sharing one GPU) stages the collectives through the host.  Never taken with "nccl"."""
+    return dist.get_backend(group) == "gloo"
+
+
+def _all_gather(recv, send, group=None):
+    if send.is_cuda and _staged(group):
+        r = torch.empty(recv.shape, dtype=recv.dtype)
+        dist.all_gather_into_tensor(r, send.cpu(), group=group)
+        recv.copy_(r)
+    else:
+        dist.all_gather_into_tensor(recv, send, group=group)
 
 
 def shard_range(n_unique, rank, world):
@@ -37,7 +53,7 @@ def allgather_records(send: torch.Tensor, n_unique: int, group=None):
     """send: uint8 [max_shard*24] holding this rank's records (padded).  Returns a list of (first_id, n, tensor)."""
     world = dist.get_world_size(group)
     recv = torch.empty(world * send.numel(), dtype=torch.uint8, device=send.device)
-    dist.all_gather_into_tensor(recv, send, group=group)
+    _all_gather(recv, send, group)
     _sync(recv)
     out = []
     for r in range(world):
@@ -47,7 +63,12 @@ def allgather_records(send: torch.Tensor, n_unique: int, group=None):
 
 
 def allreduce_flags(planes: torch.Tensor, group=None):
-    dist.all_reduce(planes, op=dist.ReduceOp.MAX, group=group)
+    if planes.is_cuda and _staged(group):
+        h = planes.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.MAX, group=group)
+        planes.copy_(h)
+    else:
+        dist.all_reduce(planes, op=dist.ReduceOp.MAX, group=group)
     _sync(planes)
     return planes
 
@@ -58,13 +79,13 @@ def allgather_edge_buckets(bucket: torch.Tensor, n_edges: int, group=None):
     world = dist.get_world_size(group)
     cnt = torch.tensor([n_edges], dtype=torch.int64, device=bucket.device)
     cnts = torch.empty(world, dtype=torch.int64, device=bucket.device)
-    dist.all_gather_into_tensor(cnts, cnt, group=group)
+    _all_gather(cnts, cnt, group)
     cnts = cnts.cpu().tolist()
     pad = max(max(cnts), 1) * EDGE_BYTES
     send = torch.zeros(pad, dtype=torch.uint8, device=bucket.device)
     send[: n_edges * EDGE_BYTES] = bucket[: n_edges * EDGE_BYTES]
     recv = torch.empty(world * pad, dtype=torch.uint8, device=bucket.device)
-    dist.all_gather_into_tensor(recv, send, group=group)
+    _all_gather(recv, send, group)
     _sync(recv)
     parts = [recv[r * pad: r * pad + cnts[r] * EDGE_BYTES] for r in range(world)]
     return torch.cat(parts) if parts else recv[:0], sum(cnts)
@@ -80,18 +101,21 @@ def run_steps23_sharded(ctx, device, group=None):
     ctx.overlap_probe_shard()
     ms = max_shard(n, world)
     send = torch.zeros(ms * RECORD_BYTES, dtype=torch.uint8, device=device)
+    _sync(send)                                   # the fill runs on torch's stream, the export on the library's
     ctx.shard_export_records(send.data_ptr(), ms)
     for first, cnt, t in allgather_records(send, n, group):
         if cnt:
             t = t.contiguous()
             ctx.shard_import_records(t.data_ptr(), first, cnt)
     planes = torch.zeros(ctx.shard_flags_bytes(), dtype=torch.uint8, device=device)
+    _sync(planes)
     ctx.shard_export_flags(planes.data_ptr())
     allreduce_flags(planes, group)
     ctx.shard_import_flags(planes.data_ptr())
     ctx.overlap_reciprocal()
     ne = ctx.shard_edges_count()
     bucket = torch.zeros(max(ne, 1) * EDGE_BYTES, dtype=torch.uint8, device=device)
+    _sync(bucket)
     ctx.shard_edges_export(bucket.data_ptr(), max(ne, 1))
     allb, total = allgather_edge_buckets(bucket, ne, group)
     allb = allb.contiguous()

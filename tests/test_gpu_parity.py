@@ -298,3 +298,23 @@ def test_fastq_gz_input_and_bad_reads(tmp_path):
     c.reads_save(rp); c.graph_save(gp)
     assert fx.md5_file(rp) == m["reads_md5"] and open(gp, "rb").read() == fx.golden_graph3("g1_clean100_k21")
     c.close()
+
+
+def test_bench_two_ranks_sharing_the_gpu_agree_with_one_rank():
+    """bench.py's N>1 path end to end (torch.distributed.run, one process per rank, sage2_amd/dist.py): on the
+    one-GPU box both ranks share cuda:0 and the collectives are staged through gloo; the canonical edge list
+    (crc32 in the JSON line, asserted equal across ranks inside bench.py) must equal the single-rank one."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--reads", "200000", "--genome", "600000", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"]
+    env = dict(os.environ, SAGE2OV_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + common, check=True, capture_output=True, text=True, timeout=240)
+    r1 = json.loads(one.stdout.strip().splitlines()[-1])
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29517", os.path.join(root, "bench.py"), "--gpus", "2"] + common,
+                         check=True, capture_output=True, text=True, timeout=240, env=env)
+    r2 = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith("{")][-1])
+    assert r2["n_gpus"] == 2 and r1["n_gpus"] == 1
+    for key in ("unique_reads", "verified_overlaps", "edges", "edges_crc32", "unresolved_reads"):
+        assert r1["config"][key] == r2["config"][key], key
+    assert r1["config"]["edges"] > 0
