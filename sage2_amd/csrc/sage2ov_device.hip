@@ -213,6 +213,7 @@ __global__ void k_order_count(const u32* __restrict__ minh, u64 n, int shift, u3
     const u64 x = (u64)blockIdx.x * blockDim.x + threadIdx.x; if (x >= n) return;
     atomicAdd(&cnt[minh[x] >> shift], 1u);
 }
+// (ordering the reads of a bucket by their position relative to the minimiser was tried: no effect on the probe kernel)
 __global__ void k_order_fill(const u32* __restrict__ minh, u64 n, u64 lo, int shift, const u32* __restrict__ offs, u32* cursor, u32* order) {
     const u64 x = (u64)blockIdx.x * blockDim.x + threadIdx.x; if (x >= n) return;
     const u32 b = minh[x] >> shift; const u32 p = atomicAdd(&cursor[b], 1u);
@@ -501,7 +502,13 @@ struct ProbeArgs {
     const u32* ids; u64 n_ids;                             // optional explicit read list (replaces [lo,hi))
     const u64* mi1; u64 TL; const u64* krec;               // minimiser index (may be null)
     u32* slow; u64 slow_cap;                               // fast kernel: reads handed to the sequential kernel (count in counters[6])
+    u64* stamps;                                           // diagnostic build (-DSAGE2OV_STAMPS): wave cycles per phase
 };
+#ifdef SAGE2OV_STAMPS
+#define STAMP(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const u64 t_ = __builtin_amdgcn_s_memtime(); st_acc[k] += t_ - st_prev; st_prev = t_; } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
 
 template <int S, int MODE, int WPB>
 __global__ __launch_bounds__(64 * WPB) void k_probe(ProbeArgs A) {
@@ -724,7 +731,6 @@ struct FastLds {                   // every string has one zero dword in front (
     u32 e[4][1 + 6 * S + 2];       // XR0 = fwd ++ right overhang, XR1 = rc(XR0), XL0 = rc ++ left overhang, XL1 = rc(XL0)
     u32 m[2][1 + 2 * S + 2];       // the two speculated longest-reach reads
     u32 candJ[FAST_CAP], candSrc[FAST_CAP];
-    u32 wh[2][32 * S];             // w-mer hashes of the read and the ping-pong buffer of the sliding minimum
 };
 __device__ __forceinline__ u32 rev2_32(u32 x) { x = __brev(x); return ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1); }
 __device__ __forceinline__ u32 mask_top32(int nb) { return nb >= 16 ? ~0u : (nb <= 0 ? 0u : (~0u << (32 - 2 * nb))); }
@@ -774,7 +780,10 @@ __device__ __forceinline__ u32 any_mismatch(const u32 (&Y)[NW], const u32* E, in
 #define SAGE2OV_FAST_WPB 8
 #endif
 template <int S, int NW, int WPL, int WPB>
-__global__ __launch_bounds__(64 * WPB, 4) void k_probe_fast(ProbeArgs A) {
+#ifndef SAGE2OV_FAST_WAVES
+#define SAGE2OV_FAST_WAVES 4
+#endif
+__global__ __launch_bounds__(64 * WPB, SAGE2OV_FAST_WAVES) void k_probe_fast(ProbeArgs A) {
     __shared__ FastLds<S> lds_all[WPB];
     FastLds<S>& L = lds_all[threadIdx.x >> 6];
     const u32 lane = lane_id();
@@ -792,19 +801,35 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_probe_fast(ProbeArgs A) {
     // keys and neighbours run on one CU, back to back
     const u64 nItems = A.ids ? A.n_ids : (A.hi > A.lo ? A.hi - A.lo : 0);
     const u32 wib = threadIdx.x >> 6;
+#ifdef SAGE2OV_STAMPS
+    u64 st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; u64 st_prev = __builtin_amdgcn_s_memtime();
+#endif
     if (lane == 0) { L.xf[0][0] = 0; L.xf[1][0] = 0; L.m[0][0] = 0; L.m[1][0] = 0; L.e[0][0] = 0; L.e[1][0] = 0; L.e[2][0] = 0; L.e[3][0] = 0; }
-    for (u64 chunk = blockIdx.x; chunk * FAST_CHUNK < nItems; chunk += gridDim.x)
-    for (u32 t0 = 0; t0 < (u32)FAST_CHUNK; t0 += WPB) {
-        // keep the block's waves on the same group of neighbouring reads (what one wave pulls in the others use at once)
+    // the wave's n-th item: chunk blockIdx.x + (n / PER) * gridDim.x, position (n % PER) * WPB + wave.  Two-deep software pipeline:
+    // the id of item n+2 and the bases of item n+1 are fetched while item n is processed (both chains off the critical path)
+    constexpr u32 PER = FAST_CHUNK / WPB;
+    auto id_of = [&](u64 n) -> u32 {
+        const u64 chunk = blockIdx.x + (n / PER) * (u64)gridDim.x, it = chunk * FAST_CHUNK + (n % PER) * WPB + wib;
+        const bool ok = it < nItems;
+        const u64 itc = ok ? it : 0;
+        const u32 v = A.ids ? A.ids[itc] : (u32)(A.lo + itc);
+        return ok ? v : 0u;                                    // 0: nothing to do (slot 0 of the read store is all zero)
+    };
+    const u32 ldw = (lane < (u32)D ? lane : 0u) ^ 1u;
+    u32 idCur = id_of(0), idNext = id_of(1);
+    u32 wNext = reads32[(u64)idCur * D + ldw];
+    for (u64 n = 0; (blockIdx.x + (n / PER) * (u64)gridDim.x) * FAST_CHUNK < nItems; n++) {
 #ifdef SAGE2OV_LOCKSTEP
         __syncthreads();       // (measured: lock step costs more than the L2 sharing it buys once the minimiser index is in place)
 #endif
-        const u64 it = chunk * FAST_CHUNK + t0 + wib;
-        if (it >= nItems) continue;
-        const u64 i = A.ids ? (u64)A.ids[it] : A.lo + it;
+        const u64 i = idCur; const u32 wCur = wNext;
+        idCur = idNext; idNext = id_of(n + 2);
+        wNext = reads32[(u64)idCur * D + ldw];
+        if (i == 0) continue;
+        STAMP(0);
         // ---------------------------------------------------------------- stage the read (big-endian dwords) + its reverse complement
         wave_sync();
-        if (lane < D) X0[lane] = reads32[i * D + (lane ^ 1)];
+        if (lane < D) X0[lane] = wCur;
         else if (lane < D + 2) { X0[lane] = 0; X1[lane] = 0; }
         wave_sync();
         const int L1 = (int)(X0[D - 1] & 0xFFFFu);
@@ -815,6 +840,7 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_probe_fast(ProbeArgs A) {
         const int nwin = L1 - h + 1;
         bool slowpath = nwin > 64 * WPL;
 
+        STAMP(1);
         // ---------------------------------------------------------------- 1. lookups
         int jj[WPL]; u32 pidx[WPL], tg[WPL]; u64 sl[WPL]; bool pend[WPL];
 #pragma unroll
@@ -826,30 +852,39 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_probe_fast(ProbeArgs A) {
             const u64 hv = hash4(k0, k1, k2, k3, seed32, four);
             pidx[q] = __umulhi((u32)(hv >> 32), Th); tg[q] = tag_of(hv);
         }
+        STAMP(2);
         if (A.mi1) {
-            // 1a. minimiser of every window: hash all w-mers once, then a sliding minimum of width m = h-w+1 by doubling
+            // 1a. minimiser of every window: hash all w-mers once (position 64c+lane in register c), then a sliding minimum of
+            //     width m = h-w+1 by doubling across lanes (ds_bpermute; no LDS storage, no barriers)
             u32 winMin[WPL];
             {
                 const int w = h < 16 ? h : 16, m = h - w + 1, npos = L1 - w + 1;
-                constexpr int NP = 32 * S;
-                for (int p0 = (int)lane; p0 < NP; p0 += 64) L.wh[0][p0] = p0 < npos ? wmer_hash(get32(X0, 2 * p0) >> (32 - 2 * w)) : ~0u;
-                wave_sync();
+                constexpr int NC = (16 * NW - 15 + 63) / 64;                      // 64-position chunks that can hold a w-mer start
+                u32 a[NC];
 #pragma unroll
-                for (int q = 0; q < WPL; q++) winMin[q] = ~0u;
-                int cur = 0, off = 0;
-                for (int bit = 0; (1 << bit) <= m; bit++) {
-                    if (m & (1 << bit)) {
+                for (int c = 0; c < NC; c++) { const int p0 = 64 * c + (int)lane; a[c] = p0 < npos ? wmer_hash(get32(X0, 2 * p0) >> (32 - 2 * w)) : ~0u; }
+                int width = 1;
+                for (; 2 * width <= m; width *= 2) {                              // a[c][l] = min over positions [p, p + 2*width)
+                    const u32 src = (lane + (u32)width) & 63u; const bool wrap = lane + (u32)width >= 64u;
+                    u32 t[NC];
 #pragma unroll
-                        for (int q = 0; q < WPL; q++) { const int p0 = 64 * q + (int)lane + off; winMin[q] = min(winMin[q], L.wh[cur][p0 < NP ? p0 : NP - 1]); }
-                        off += 1 << bit;
-                    }
-                    if ((2 << bit) <= m) {       // next level: width doubles
-                        for (int p0 = (int)lane; p0 < NP; p0 += 64) { const int p1 = p0 + (1 << bit); L.wh[cur ^ 1][p0] = min(L.wh[cur][p0], L.wh[cur][p1 < NP ? p1 : NP - 1]); }
-                        wave_sync();
-                        cur ^= 1;
-                    }
+                    for (int c = 0; c < NC; c++) t[c] = (u32)__shfl((int)a[c], (int)src);
+#pragma unroll
+                    for (int c = 0; c < NC; c++) a[c] = min(a[c], wrap ? (c + 1 < NC ? t[c + 1] : ~0u) : t[c]);
+                }
+                if (m > width) {                                                  // [p, p+m) = [p, p+width) U [p+m-width, p+m)
+                    const u32 sh = (u32)(m - width), src = (lane + sh) & 63u; const bool wrap = lane + sh >= 64u;
+                    u32 t[NC];
+#pragma unroll
+                    for (int c = 0; c < NC; c++) t[c] = (u32)__shfl((int)a[c], (int)src);
+#pragma unroll
+                    for (int q = 0; q < WPL; q++) winMin[q] = q < NC ? min(a[q < NC ? q : 0], wrap ? (q + 1 < NC ? t[q + 1 < NC ? q + 1 : 0] : ~0u) : t[q < NC ? q : 0]) : ~0u;   // (windows past the last chunk do not exist)
+                } else {
+#pragma unroll
+                    for (int q = 0; q < WPL; q++) winMin[q] = q < NC ? a[q < NC ? q : 0] : ~0u;
                 }
             }
+            STAMP(3);
             // 1b. group of the minimiser (lanes that share a minimiser read the same words), then a scan of the group
             u32 goff[WPL], gn[WPL]; const u32 TL32 = (u32)A.TL;
             {
@@ -874,6 +909,7 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_probe_fast(ProbeArgs A) {
                     }
                 }
             }
+            STAMP(4);
             u32 nmax = 0;
 #pragma unroll
             for (int q = 0; q < WPL; q++) { if (gn[q] == MI_BIG) gn[q] = 0; else if (pend[q]) { pend[q] = false; nmax = max(nmax, gn[q]); } else gn[q] = 0; }
@@ -882,19 +918,29 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_probe_fast(ProbeArgs A) {
             wmax = max(wmax, dpp_mov<0x111, 0xF>(0, wmax)); wmax = max(wmax, dpp_mov<0x112, 0xF>(0, wmax)); wmax = max(wmax, dpp_mov<0x114, 0xF>(0, wmax)); wmax = max(wmax, dpp_mov<0x118, 0xF>(0, wmax));
             wmax = max(wmax, dpp_mov<0x142, 0xA>(0, wmax)); wmax = max(wmax, dpp_mov<0x143, 0xC>(0, wmax));
             wmax = (u32)__builtin_amdgcn_readlane((int)wmax, 63);
-            u32 nmatch[WPL];
+            // the scan reads only the high dword of a record (tag | count | top payload bit): 16 records per window in flight,
+            // so groups of up to 16 keys cost one round trip; the matching record is then read whole (its sector is in L1 by now)
+            u32 nmatch[WPL], mpos[WPL];
 #pragma unroll
-            for (int q = 0; q < WPL; q++) nmatch[q] = 0;
-            for (u32 x = 0; x < wmax; x += 8) {                                  // 8 independent loads per window and step
-                u64 r[WPL][8];
+            for (int q = 0; q < WPL; q++) { nmatch[q] = 0; mpos[q] = 0; }
+            const u32* krecHi = (const u32*)A.krec + 1;
+            for (u32 x = 0; x < wmax; x += 16) {
+                u32 r[WPL][16];
 #pragma unroll
                 for (int q = 0; q < WPL; q++)
 #pragma unroll
-                    for (int u = 0; u < 8; u++) r[q][u] = A.krec[goff[q] + (x + u < gn[q] ? x + u : 0u)];
+                    for (int u = 0; u < 16; u++) r[q][u] = krecHi[2 * (size_t)(goff[q] + (x + u < gn[q] ? x + u : 0u))];
 #pragma unroll
                 for (int q = 0; q < WPL; q++)
 #pragma unroll
-                    for (int u = 7; u >= 0; u--) if (x + u < gn[q] && (u32)(r[q][u] >> SLOT_TAG_SHIFT) == tg[q]) { sl[q] = r[q][u]; nmatch[q]++; }
+                    for (int u = 15; u >= 0; u--) if (x + u < gn[q] && (r[q][u] >> (SLOT_TAG_SHIFT - 32)) == tg[q]) { mpos[q] = x + u; nmatch[q]++; }
+            }
+            {
+                u64 rec[WPL];
+#pragma unroll
+                for (int q = 0; q < WPL; q++) rec[q] = A.krec[goff[q] + mpos[q]];
+#pragma unroll
+                for (int q = 0; q < WPL; q++) if (nmatch[q]) sl[q] = rec[q];
             }
             // two records of one group with the same tag (two keys, ~2^-24 per pair): the scan cannot tell them apart
             bool amb = false;
@@ -921,6 +967,7 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_probe_fast(ProbeArgs A) {
                 }
             }
         }
+        STAMP(5);
         // ---------------------------------------------------------------- 2. candidates
         u32 cnt[WPL], pay[WPL], mine = 0;
 #pragma unroll
@@ -968,6 +1015,7 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_probe_fast(ProbeArgs A) {
                 myL2[q] = (int)(((const u32*)yp)[2 * S - 2] & 0xFFFFu);     // low dword of the last word
                 if (NW == D) Y[q][NW - 1] &= 0xFFFF0000u;
             }
+            STAMP(6);
             // ---------------------------------------------------------------- 3. speculation: furthest reach per side
             u32 reachR = ~0u, reachL = ~0u; bool sameLen = true;
 #pragma unroll
@@ -1037,6 +1085,7 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_probe_fast(ProbeArgs A) {
                 }
                 wave_sync();
             }
+            STAMP(7);
             if (!slowpath) {
                 // ---------------------------------------------------------------- 4. one whole-length compare per candidate
                 bool bad = false;
@@ -1082,6 +1131,7 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_probe_fast(ProbeArgs A) {
                 if (__any(bad)) slowpath = true;
             }
         }
+        STAMP(8);
         if (slowpath) {
             if (lane == 0) { u64 p = atomicAdd(&A.counters[6], 1ull); if (p < A.slow_cap) A.slow[p] = (u32)i; }
         } else {
@@ -1102,7 +1152,11 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_probe_fast(ProbeArgs A) {
             }
             if (lane == 0) { A.right[i] = rv; A.left[i] = lv; A.conn[i] = nhits; }
         }
+        STAMP(9);
     }
+#ifdef SAGE2OV_STAMPS
+    if (A.stamps && lane == 0) for (int x = 0; x < 10; x++) atomicAdd(&A.stamps[x], st_acc[x]);
+#endif
 }
 
 // =============================================================================================
@@ -1426,6 +1480,11 @@ int dev_probe(Device* d, uint64_t lo, uint64_t hi, std::string& err) {
         const int nwinMax = d->maxL - d->h + 1;                               // windows of the longest read
         if (!getenv("SAGE2OV_NO_LOCALITY")) { u32* order = nullptr; int rc = build_locality_order(d, lo, hi, &order, err); if (rc) return rc; A.ids = order; A.n_ids = nreads; }
         const unsigned blocks = (unsigned)std::min<u64>((nreads + FAST_CHUNK - 1) / FAST_CHUNK, 256ull * 16);
+#ifdef SAGE2OV_STAMPS
+        static u64* d_stamps = nullptr;
+        if (!d_stamps) HIPCHK(hipMalloc(&d_stamps, 10 * sizeof(u64)));
+        HIPCHK(hipMemsetAsync(d_stamps, 0, 10 * sizeof(u64), d->stream)); A.stamps = d_stamps;
+#endif
         HIPCHK(hipEventRecord(d->ev[2], d->stream));
         bool launched = true;
         constexpr int FW = SAGE2OV_FAST_WPB;      // waves per block: a whole CU's worth works on one locality chunk
@@ -1443,6 +1502,10 @@ int dev_probe(Device* d, uint64_t lo, uint64_t hi, std::string& err) {
         HIPCHK(hipStreamSynchronize(d->stream));
         float ms = 0; hipEventElapsedTime(&ms, d->ev[2], d->ev[3]); d->tm.probe_kernel_ms += ms; d->tm.probe_launches++;
         d->tm.slow_reads += nslow;
+#ifdef SAGE2OV_STAMPS
+        { u64 st[10]; HIPCHK(hipMemcpy(st, d_stamps, sizeof st, hipMemcpyDeviceToHost)); u64 tot = 0; for (u64 v : st) tot += v;
+          fprintf(stderr, "[stamps] kernel %.2f ms; share of wave cycles:", ms); for (int x = 0; x < 10; x++) fprintf(stderr, " %d:%.1f%%", x, 100.0 * (double)st[x] / (double)tot); fprintf(stderr, "\n"); }
+#endif
         if (nslow) {                                                          // ambiguous / overflowing reads: sequential state machine
             ProbeArgs B = base_args(d); B.ids = slow; B.n_ids = nslow;
             int rc = launch_probe<0>(d, B, err); if (rc) return rc;
