@@ -723,6 +723,7 @@ __global__ __launch_bounds__(64 * WPB) void k_probe(ProbeArgs A) {
 //      position classifies it as hit+consistent / not a hit / hit but inconsistent
 //   5. DPP wave reductions pick the extension records
 // =============================================================================================
+constexpr u64 MI_SCAN_PAD = 272;   // records behind krec[]: the scan of a small group runs up to the wave's largest group (< 255) rounded up to 16
 constexpr int FAST_CAP = 128;
 constexpr int FAST_CHUNK = 64;     // reads per block visit
 template <int S>
@@ -781,7 +782,7 @@ __device__ __forceinline__ u32 any_mismatch(const u32 (&Y)[NW], const u32* E, in
 #endif
 template <int S, int NW, int WPL, int WPB>
 #ifndef SAGE2OV_FAST_WAVES
-#define SAGE2OV_FAST_WAVES 4
+#define SAGE2OV_FAST_WAVES 5
 #endif
 __global__ __launch_bounds__(64 * WPB, SAGE2OV_FAST_WAVES) void k_probe_fast(ProbeArgs A) {
     __shared__ FastLds<S> lds_all[WPB];
@@ -800,7 +801,7 @@ __global__ __launch_bounds__(64 * WPB, SAGE2OV_FAST_WAVES) void k_probe_fast(Pro
     // a block owns FAST_CHUNK consecutive positions of the (locality ordered) id list at a time, so reads that share
     // keys and neighbours run on one CU, back to back
     const u64 nItems = A.ids ? A.n_ids : (A.hi > A.lo ? A.hi - A.lo : 0);
-    const u32 wib = threadIdx.x >> 6;
+    const u32 wib = (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // wave-uniform: loop bookkeeping stays on the scalar unit
 #ifdef SAGE2OV_STAMPS
     u64 st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; u64 st_prev = __builtin_amdgcn_s_memtime();
 #endif
@@ -808,8 +809,8 @@ __global__ __launch_bounds__(64 * WPB, SAGE2OV_FAST_WAVES) void k_probe_fast(Pro
     // the wave's n-th item: chunk blockIdx.x + (n / PER) * gridDim.x, position (n % PER) * WPB + wave.  Two-deep software pipeline:
     // the id of item n+2 and the bases of item n+1 are fetched while item n is processed (both chains off the critical path)
     constexpr u32 PER = FAST_CHUNK / WPB;
-    auto id_of = [&](u64 n) -> u32 {
-        const u64 chunk = blockIdx.x + (n / PER) * (u64)gridDim.x, it = chunk * FAST_CHUNK + (n % PER) * WPB + wib;
+    auto id_of = [&](u32 n) -> u32 {
+        const u64 chunk = blockIdx.x + (u64)(n / PER) * gridDim.x, it = chunk * FAST_CHUNK + (n % PER) * WPB + wib;
         const bool ok = it < nItems;
         const u64 itc = ok ? it : 0;
         const u32 v = A.ids ? A.ids[itc] : (u32)(A.lo + itc);
@@ -818,7 +819,7 @@ __global__ __launch_bounds__(64 * WPB, SAGE2OV_FAST_WAVES) void k_probe_fast(Pro
     const u32 ldw = (lane < (u32)D ? lane : 0u) ^ 1u;
     u32 idCur = id_of(0), idNext = id_of(1);
     u32 wNext = reads32[(u64)idCur * D + ldw];
-    for (u64 n = 0; (blockIdx.x + (n / PER) * (u64)gridDim.x) * FAST_CHUNK < nItems; n++) {
+    for (u32 n = 0; (blockIdx.x + (u64)(n / PER) * gridDim.x) * FAST_CHUNK < nItems; n++) {
 #ifdef SAGE2OV_LOCKSTEP
         __syncthreads();       // (measured: lock step costs more than the L2 sharing it buys once the minimiser index is in place)
 #endif
@@ -918,29 +919,37 @@ __global__ __launch_bounds__(64 * WPB, SAGE2OV_FAST_WAVES) void k_probe_fast(Pro
             wmax = max(wmax, dpp_mov<0x111, 0xF>(0, wmax)); wmax = max(wmax, dpp_mov<0x112, 0xF>(0, wmax)); wmax = max(wmax, dpp_mov<0x114, 0xF>(0, wmax)); wmax = max(wmax, dpp_mov<0x118, 0xF>(0, wmax));
             wmax = max(wmax, dpp_mov<0x142, 0xA>(0, wmax)); wmax = max(wmax, dpp_mov<0x143, 0xC>(0, wmax));
             wmax = (u32)__builtin_amdgcn_readlane((int)wmax, 63);
-            // the scan reads only the high dword of a record (tag | count | top payload bit): 16 records per window in flight,
-            // so groups of up to 16 keys cost one round trip; the matching record is then read whole (its sector is in L1 by now)
+            // The scan reads only the high dword of a record (tag | count | top payload bit), 16 records per window in flight
+            // off one base pointer (immediate offsets, no address arithmetic).  It does not stop at the end of the group: a record
+            // of a neighbouring group that happens to carry the tag (2^-24) only adds candidates that fail verification, like
+            // any merged tag, or makes the window ambiguous (-> sequential kernel).  krec[] is padded by 16 records for this.
             u32 nmatch[WPL], mpos[WPL];
 #pragma unroll
             for (int q = 0; q < WPL; q++) { nmatch[q] = 0; mpos[q] = 0; }
-            const u32* krecHi = (const u32*)A.krec + 1;
-            for (u32 x = 0; x < wmax; x += 16) {
-                u32 r[WPL][16];
+            {
+                const u32* kp[WPL]; u32 tgs[WPL];
 #pragma unroll
-                for (int q = 0; q < WPL; q++)
+                for (int q = 0; q < WPL; q++) { kp[q] = (const u32*)(A.krec + goff[q]) + 1; tgs[q] = tg[q] << (SLOT_TAG_SHIFT - 32); }
+                for (u32 x = 0; x < wmax; x += 16) {
+                    u32 r[WPL][16];
 #pragma unroll
-                    for (int u = 0; u < 16; u++) r[q][u] = krecHi[2 * (size_t)(goff[q] + (x + u < gn[q] ? x + u : 0u))];
+                    for (int q = 0; q < WPL; q++)
 #pragma unroll
-                for (int q = 0; q < WPL; q++)
+                        for (int u = 0; u < 16; u++) r[q][u] = kp[q][2 * u];
 #pragma unroll
-                    for (int u = 15; u >= 0; u--) if (x + u < gn[q] && (r[q][u] >> (SLOT_TAG_SHIFT - 32)) == tg[q]) { mpos[q] = x + u; nmatch[q]++; }
+                    for (int q = 0; q < WPL; q++) {
+#pragma unroll
+                        for (int u = 15; u >= 0; u--) { const bool hit = (r[q][u] ^ tgs[q]) < (1u << (SLOT_TAG_SHIFT - 32)); mpos[q] = hit ? x + (u32)u : mpos[q]; nmatch[q] += hit ? 1u : 0u; }
+                        kp[q] += 32;
+                    }
+                }
             }
             {
                 u64 rec[WPL];
 #pragma unroll
                 for (int q = 0; q < WPL; q++) rec[q] = A.krec[goff[q] + mpos[q]];
 #pragma unroll
-                for (int q = 0; q < WPL; q++) if (nmatch[q]) sl[q] = rec[q];
+                for (int q = 0; q < WPL; q++) if (nmatch[q] && gn[q]) sl[q] = rec[q];
             }
             // two records of one group with the same tag (two keys, ~2^-24 per pair): the scan cannot tell them apart
             bool amb = false;
@@ -990,8 +999,13 @@ __global__ __launch_bounds__(64 * WPB, SAGE2OV_FAST_WAVES) void k_probe_fast(Pro
             wave_sync();
             // ---- gather: entry (CSR for multi-entry buckets), then the 64-byte read slot, two candidates per lane
             u32 Y[2][NW]; bool gate[2];
+            const bool two = total > 64u;                // the second slot of every lane is empty otherwise: skip its work (wave-uniform)
+            gate[1] = false;
+#pragma unroll
+            for (int c = 0; c < NW; c++) Y[1][c] = 0;
 #pragma unroll
             for (int q = 0; q < 2; q++) {
+                if (q == 1 && !two) continue;
                 const u32 ci = lane + 64 * q; const bool have = ci < total;
                 const u32 cjj = L.candJ[have ? ci : 0], src = L.candSrc[have ? ci : 0];
                 const bool isCsr = (cjj & 0x80000000u) != 0;
@@ -1002,6 +1016,7 @@ __global__ __launch_bounds__(64 * WPB, SAGE2OV_FAST_WAVES) void k_probe_fast(Pro
             }
 #pragma unroll
             for (int q = 0; q < 2; q++) {
+                if (q == 1 && !two) continue;
                 // 16-byte loads of the (at least 32-byte aligned) slot; gated-off lanes read slot 0 (zeros, always cached)
                 const uint4* yp = (const uint4*)(A.reads + (gate[q] ? (u64)(myEnt[q] >> 2) : 0ull) * S);
 #pragma unroll
@@ -1020,6 +1035,7 @@ __global__ __launch_bounds__(64 * WPB, SAGE2OV_FAST_WAVES) void k_probe_fast(Pro
             u32 reachR = ~0u, reachL = ~0u; bool sameLen = true;
 #pragma unroll
             for (int q = 0; q < 2; q++) {
+                if (q == 1 && !two) continue;
                 if (gate[q]) {
                     const int t = myEnt[q] & 3; const u32 ci = lane + 64 * q;
                     if (t == 0 || t == 2) reachR = min(reachR, ((u32)(0x7FF - (myJ[q] + myL2[q])) << 7) | ci);
@@ -1092,6 +1108,7 @@ __global__ __launch_bounds__(64 * WPB, SAGE2OV_FAST_WAVES) void k_probe_fast(Pro
                 const int clU = L1 >> 4; const u32 tailU = mask_top32(L1 & 15);
 #pragma unroll
                 for (int q = 0; q < 2; q++) {
+                    if (q == 1 && !two) continue;
                     bool hit = false;
                     if (gate[q]) {
                         const int t = myEnt[q] & 3, j = myJ[q], L2 = myL2[q];
@@ -1388,7 +1405,8 @@ int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t
     // ---- stage B: minimiser groups over the distinct-key records
     d->mi1 = nullptr; d->krec = nullptr; d->TL = 0;
     if (wantMI && d->n_keys > 0) {
-        WS(krec, u64, WS_KREC, d->n_keys + 1);
+        WS(krec, u64, WS_KREC, d->n_keys + MI_SCAN_PAD);
+        HIPCHK(hipMemsetAsync(krec + d->n_keys, 0, MI_SCAN_PAD * sizeof(u64), d->stream));   // the probe scan may run past the last group: empty records
         hipLaunchKernelGGL(k_mi_alloc, dim3(grid_for(TL, ALLOC_ITEMS)), dim3(256), 0, d->stream, mi1, TL, mcnt, d->d_counters + 8);
         hipLaunchKernelGGL(k_mi_fill, dim3(grid_for(d->T, 256)), dim3(256), 0, d->stream, d->slots, d->T, slot_mh, mi1, mcur, krec);
         u64 mc[3];

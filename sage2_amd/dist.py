@@ -14,8 +14,7 @@ binds it to a sage2_amd.Context.
 import torch
 import torch.distributed as dist
 
-RECORD_BYTES = 24
-EDGE_BYTES = 16
+from .shard import RECORD_BYTES, EDGE_BYTES, shard_range, max_shard  # noqa: F401  (re-exported)
 
 
 def _sync(t: torch.Tensor):
@@ -38,15 +37,6 @@ def _all_gather(recv, send, group=None):
         recv.copy_(r)
     else:
         dist.all_gather_into_tensor(recv, send, group=group)
-
-
-def shard_range(n_unique, rank, world):
-    """ids [lo, hi) of rank `rank`; identical to sage2ov_shard_range."""
-    return 1 + (n_unique * rank) // world, 1 + (n_unique * (rank + 1)) // world
-
-
-def max_shard(n_unique, world):
-    return max(shard_range(n_unique, r, world)[1] - shard_range(n_unique, r, world)[0] for r in range(world))
 
 
 def allgather_records(send: torch.Tensor, n_unique: int, group=None):

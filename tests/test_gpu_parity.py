@@ -195,7 +195,7 @@ def test_sharded_contexts_on_one_gpu_match_reference(name, world, tmp_path):
     """The multi-GPU path without a cluster (SURVEY section 4): `world` rank contexts on ONE GPU, the collectives
     replaced by explicit concatenation / element-wise max of the very buffers the C ABI exports and imports.
     Every rank must end with the reference's P.graph3."""
-    from sage2_amd.dist import RECORD_BYTES, EDGE_BYTES, shard_range, max_shard
+    from sage2_amd.shard import RECORD_BYTES, EDGE_BYTES, shard_range, max_shard      # torch-free on purpose: this process only uses the C ABI
     m = fx.golden(name)
     bases, off = fx.make_reads(m["synth"])
     hip = _Hip()
