@@ -738,7 +738,9 @@ __device__ __forceinline__ u32 mask_top32(int nb) { return nb >= 16 ? ~0u : (nb 
 __device__ __forceinline__ u32 range_mask32(int lo, int hi) { return mask_top32(hi) & ~mask_top32(lo); }
 __device__ __forceinline__ u32 funnel32(u32 a, u32 b, int r) { return (u32)(((((u64)a) << 32) | b) >> (32 - r)); }   // r in [0,31]
 // 32 bits at bit position p of a big-endian dword string whose dword 0 sits at D[0]; p >= -32 when D[-1] is the zero pad
-__device__ __forceinline__ u32 get32(const u32* D, int p) { const int q = p >> 5; return funnel32(D[q], D[q + 1], p & 31); }
+// One v_alignbit_b32 ({hi,lo} >> s, s in [0,31]): with q = (p-1)>>5 and s = (-p)&31 the aligned case (p%32 == 0) reads
+// the wanted dword as `lo` with s = 0, every other case is the usual funnel.  (D[q] is touched but unused when aligned.)
+__device__ __forceinline__ u32 get32(const u32* D, int p) { const int q = (p - 1) >> 5; return __builtin_amdgcn_alignbit(D[q], D[q + 1], (u32)(-p) & 31u); }
 // same with bounds: anything outside [0, 32*n) reads as zero, p may be any negative number (slow, rare paths only)
 __device__ __forceinline__ u32 get32z(const u32* D, int n, int p) {
     const int pp = p < 0 ? 0 : p, sh = pp - p, q = pp >> 5;
@@ -765,12 +767,12 @@ __device__ __forceinline__ u32 wave_min_dpp(u32 v) {                 // result v
 // partial one, tailMask its valid bits.  When they are wave-uniform the masks cost nothing per dword.
 template <int NW>
 __device__ __forceinline__ u32 any_mismatch(const u32 (&Y)[NW], const u32* E, int d, int cl, u32 tailMask) {
-    const int q = (2 * d) >> 5, r = (2 * d) & 31;
+    const int q = (2 * d - 1) >> 5; const u32 sh = (u32)(-2 * d) & 31u;       // see get32
     u32 acc = 0, nxt = E[q + NW];
 #pragma unroll
     for (int c = NW - 1; c >= 0; c--) {
         const u32 cur = E[q + c];
-        const u32 diff = Y[c] ^ funnel32(cur, nxt, r);
+        const u32 diff = Y[c] ^ __builtin_amdgcn_alignbit(cur, nxt, sh);
         acc |= (c < cl) ? diff : (c == cl ? (diff & tailMask) : 0u);
         nxt = cur;
     }
@@ -782,7 +784,7 @@ __device__ __forceinline__ u32 any_mismatch(const u32 (&Y)[NW], const u32* E, in
 #endif
 template <int S, int NW, int WPL, int WPB>
 #ifndef SAGE2OV_FAST_WAVES
-#define SAGE2OV_FAST_WAVES 5
+#define SAGE2OV_FAST_WAVES 4
 #endif
 __global__ __launch_bounds__(64 * WPB, SAGE2OV_FAST_WAVES) void k_probe_fast(ProbeArgs A) {
     __shared__ FastLds<S> lds_all[WPB];
@@ -1086,7 +1088,7 @@ __global__ __launch_bounds__(64 * WPB, SAGE2OV_FAST_WAVES) void k_probe_fast(Pro
                         const int cb = 16 * c;
                         const int pB = 2 * (cb - sB);                                       // bit position in B; >= -32 is readable (front pad)
                         const u32 va = Aa[c];
-                        const u32 vb = pB >= -32 ? get32(Bb, pB) : 0u;
+                        const u32 vb = pB > -32 ? get32(Bb, pB) : 0u;
                         const u32 mA = mask_top32(lenA - cb);
                         dstA[c] = ((va & mA) | (vb & ~mA)) & mask_top32(tot - cb);
                         wave_sync();
