@@ -249,23 +249,50 @@ __global__ void k_index_count_v(const u64* __restrict__ reads, u64 N, int S, int
         where[e] = (u32)idx;
     }
 }
-__global__ void k_index_count(const u64* __restrict__ reads, u64 N, int S, int h, u64 seed, u64* slots, u64 T, u32* cnt, u32* where, u64* dbg) {
+// During the build a slot is tag:24 | number of entries seen so far:40 and a group word is mtag:24 | number of keys so far:40:
+// claiming and counting are one atomic on one word, and the value the atomic returns is the entry's rank inside its bucket
+// (the key's rank inside its group), so the fill kernel needs no cursors.  k_index_alloc / k_mi_alloc rewrite the words
+// into their final form.
+constexpr u64 BUILD_CNT_MASK = (1ull << SLOT_TAG_SHIFT) - 1;
+__device__ __forceinline__ u64 mi_claim_count(u64* mi1, u64 TL, u32 mh, u32& rank) {
+    const u64 mt = minim_tag(mh); u64 idx = __umulhi(mh, (u32)TL);
+    for (u32 step = 0; step < 2048u; step++) {
+        u64 v = __hip_atomic_load(&mi1[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v == 0) {
+            v = atomicCAS((u64*)&mi1[idx], 0ull, (mt << SLOT_TAG_SHIFT) | 1ull);
+            if (v == 0) { rank = 0; return idx; }
+        }
+        if ((v >> SLOT_TAG_SHIFT) == mt) { rank = (u32)(atomicAdd((u64*)&mi1[idx], 1ull) & BUILD_CNT_MASK); return idx; }
+        if (++idx == TL) idx = 0;
+    }
+    return ~0ull;                                                      // table too crowded: the caller gives the minimiser index up
+}
+__global__ void k_index_count(const u64* __restrict__ reads, u64 N, int S, int h, u64 seed, u64* slots, u64 T, u64* where, u64* dbg,
+                              u64* slot_g, u64* mi1, u64 TL, u64* micounters) {
     u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     const u64 stride = (u64)gridDim.x * blockDim.x;
     for (; e < 4 * N; e += stride) {
         u64 hi, lo; entry_key(reads, S, h, (e >> 2) + 1, (int)(e & 3), hi, lo);
         u64 hv = hash_key(hi, lo, h, seed); const u64 tag = tag_of(hv); u64 idx = home_of(hv, T);
         if (dbg) { dbg[4 * e] = hi; dbg[4 * e + 1] = lo; dbg[4 * e + 2] = hv; dbg[4 * e + 3] = idx; }
+        u64 rank = 0;
         for (;;) {
             u64 s = __hip_atomic_load(&slots[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (s == 0) {
-                u64 old = atomicCAS((u64*)&slots[idx], 0ull, tag << SLOT_TAG_SHIFT);
-                if (old == 0 || (old >> SLOT_TAG_SHIFT) == tag) break;
-            } else if ((s >> SLOT_TAG_SHIFT) == tag) break;
+                s = atomicCAS((u64*)&slots[idx], 0ull, (tag << SLOT_TAG_SHIFT) | 1ull);
+                if (s == 0) break;                                     // claimed: rank 0
+            }
+            if ((s >> SLOT_TAG_SHIFT) == tag) { rank = atomicAdd((u64*)&slots[idx], 1ull) & BUILD_CNT_MASK; break; }
             if (++idx == T) idx = 0;
         }
-        atomicAdd(&cnt[idx], 1u);
-        where[e] = (u32)idx;
+        where[e] = idx | (rank << 32);                                 // (ranks beyond 2^32 cannot occur: 4N < 2^32 entries)
+        if (slot_g && rank == 0) {                                     // one thread per bucket, key still in registers: its minimiser group (stage B)
+            u32 k0, k1, k2, k3; key_left_align(hi, lo, h, k0, k1, k2, k3);
+            u32 grank = 0;
+            const u64 g = mi_claim_count(mi1, TL, minim_hash(key_min_hash(k0, k1, k2, k3, h), (u32)seed), grank);
+            if (g == ~0ull) { atomicAdd(&micounters[7], 1ull); slot_g[idx] = ~0ull; }
+            else slot_g[idx] = g | ((u64)grank << 32);
+        }
     }
 }
 __global__ void k_debug_table(const u64* __restrict__ slots, u64 T, u64* out) {
@@ -289,14 +316,14 @@ __device__ __forceinline__ u32 block_excl_scan(u32 v, u32* sh, u32& total);
 // One block owns ALLOC_ITEMS consecutive slots and draws its CSR space with ONE atomic (a per-wave atomic on
 // the same word serialises: 25 ms for 68 M slots; this form streams at HBM speed).
 constexpr int ALLOC_PER_THREAD = 16, ALLOC_ITEMS = 256 * ALLOC_PER_THREAD;
-__global__ __launch_bounds__(256) void k_index_alloc(u64* slots, u64 T, const u32* __restrict__ cnt, u64* counters, u64* big, u32 big_cap) {
+__global__ __launch_bounds__(256) void k_index_alloc(u64* slots, u64 T, u64* counters, u64* big, u32 big_cap) {
     __shared__ u32 sh[4]; __shared__ u64 shBase;
     const u64 base0 = (u64)blockIdx.x * ALLOC_ITEMS;
     u32 c[ALLOC_PER_THREAD]; u32 need = 0, occ = 0;
 #pragma unroll
     for (int x = 0; x < ALLOC_PER_THREAD; x++) {
         const u64 idx = base0 + (u64)x * 256 + threadIdx.x;
-        c[x] = idx < T ? cnt[idx] : 0u;
+        c[x] = idx < T ? (u32)(slots[idx] & BUILD_CNT_MASK) : 0u;
         need += c[x] >= 2 ? c[x] : 0u; occ += c[x] != 0;
     }
     u32 total; u32 excl = block_excl_scan(need, sh, total);
@@ -306,6 +333,7 @@ __global__ __launch_bounds__(256) void k_index_alloc(u64* slots, u64 T, const u3
     u64 start = shBase + excl;
 #pragma unroll
     for (int x = 0; x < ALLOC_PER_THREAD; x++) {
+        if (c[x] == 1) { const u64 idx = base0 + (u64)x * 256 + threadIdx.x; slots[idx] &= ~0ull << SLOT_TAG_SHIFT; }   // single entry: the fill kernel writes it inline
         if (c[x] >= 2) {
             const u64 idx = base0 + (u64)x * 256 + threadIdx.x;
             const u32 c7 = c[x] >= HASH_THRESHOLD ? SLOT_CNT_LONG : c[x];
@@ -318,24 +346,23 @@ __global__ __launch_bounds__(256) void k_index_alloc(u64* slots, u64 T, const u3
         }
     }
 }
-__device__ __forceinline__ u64 mi_find_or_claim(u64* mi1, u64 TL, u32 mh, bool claim);
-__global__ void k_index_fill(const u64* __restrict__ reads, u64 N, int S, int h, u32 seed, u64* slots, u32* cnt, const u32* __restrict__ where, u32* csr, u32* slot_mh,
-                             u64* mi1, u64 TL, u32* mcnt, u64* micounters) {
+__global__ void k_index_fill(u64 N, u64* slots, const u64* __restrict__ where, u32* csr,
+                             const u64* __restrict__ slot_g, const u64* __restrict__ mi1, u64* krec) {
     u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     const u64 stride = (u64)gridDim.x * blockDim.x;
     for (; e < 4 * N; e += stride) {
-        u64 idx = where[e]; u64 s = slots[idx];
-        u32 c7 = (u32)(s >> SLOT_CNT_SHIFT) & 127u;
-        u32 entry = (u32)(((e >> 2) + 1) * 4 + (e & 3));
-        bool designated;
-        if (c7 == 0) { slots[idx] = (s & (~0ull << SLOT_TAG_SHIFT)) | (1ull << SLOT_CNT_SHIFT) | entry; designated = true; }   // the only entry: inline
-        else { u32 pos = atomicSub(&cnt[idx], 1u) - 1u; csr[(s & SLOT_PAY_MASK) + pos] = entry; designated = pos == 0; }
-        if (slot_mh && designated) {                                   // one entry per bucket: claim / count the minimiser group of its key (stage B)
-            u64 hi, lo; entry_key(reads, S, h, (e >> 2) + 1, (int)(e & 3), hi, lo);
-            u32 k0, k1, k2, k3; key_left_align(hi, lo, h, k0, k1, k2, k3);
-            const u64 g = mi_find_or_claim(mi1, TL, minim_hash(key_min_hash(k0, k1, k2, k3, h), seed), true);
-            if (g == ~0ull) atomicAdd(&micounters[7], 1ull); else atomicAdd(&mcnt[g], 1u);
-            slot_mh[idx] = (u32)g;                                     // group slot of this bucket (0xFFFFFFFF: none)
+        const u64 wv = where[e]; const u64 idx = wv & 0xFFFFFFFFull; const u32 rank = (u32)(wv >> 32);
+        u64 s = slots[idx];
+        const u32 c7 = (u32)(s >> SLOT_CNT_SHIFT) & 127u;
+        const u32 entry = (u32)(((e >> 2) + 1) * 4 + (e & 3));
+        if (c7 == 0) { s = (s & (~0ull << SLOT_TAG_SHIFT)) | (1ull << SLOT_CNT_SHIFT) | entry; slots[idx] = s; }   // the only entry: inline
+        else csr[(s & SLOT_PAY_MASK) + rank] = entry;
+        if (slot_g && rank == 0) {                                     // one entry per bucket: the bucket's record goes into its minimiser group (stage B)
+            const u64 sg = slot_g[idx];
+            if (sg != ~0ull) {
+                const u64 v = mi1[(u32)sg];
+                if (((v >> 32) & 255u) != MI_BIG) krec[(u32)v + (u32)(sg >> 32)] = s;      // (oversized groups are never scanned)
+            }
         }
     }
 }
@@ -361,25 +388,12 @@ __global__ void k_index_purity(const u64* __restrict__ reads, int S, int h, cons
 }
 // ---- stage B of the index build: group the distinct-key records of the uniform table by minimiser
 // bounded: a full group table (more distinct minimisers than expected) must never spin forever; ~0 = gave up
-__device__ __forceinline__ u64 mi_find_or_claim(u64* mi1, u64 TL, u32 mh, bool claim) {
-    const u64 mt = minim_tag(mh); u64 idx = __umulhi(mh, (u32)TL);
-    for (u32 step = 0; step < 2048u; step++) {
-        u64 v = __hip_atomic_load(&mi1[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (v == 0) {
-            if (!claim) return ~0ull;
-            const u64 old = atomicCAS((u64*)&mi1[idx], 0ull, mt << SLOT_TAG_SHIFT);
-            if (old == 0 || (old >> SLOT_TAG_SHIFT) == mt) return idx;
-        } else if ((v >> SLOT_TAG_SHIFT) == mt) return idx;
-        if (++idx == TL) idx = 0;
-    }
-    return ~0ull;
-}
-__global__ __launch_bounds__(256) void k_mi_alloc(u64* mi1, u64 TL, const u32* __restrict__ mcnt, u64* counters) {   // counters[5]: records placed, [6]: groups
+__global__ __launch_bounds__(256) void k_mi_alloc(u64* mi1, u64 TL, u64* counters) {   // counters[5]: records placed, [6]: groups
     __shared__ u32 sh[4]; __shared__ u64 shBase;
     const u64 base0 = (u64)blockIdx.x * ALLOC_ITEMS;
     u32 c[ALLOC_PER_THREAD]; u32 need = 0, occ = 0;
 #pragma unroll
-    for (int x = 0; x < ALLOC_PER_THREAD; x++) { const u64 idx = base0 + (u64)x * 256 + threadIdx.x; c[x] = idx < TL ? mcnt[idx] : 0u; need += c[x]; occ += c[x] != 0; }
+    for (int x = 0; x < ALLOC_PER_THREAD; x++) { const u64 idx = base0 + (u64)x * 256 + threadIdx.x; c[x] = idx < TL ? (u32)(mi1[idx] & BUILD_CNT_MASK) : 0u; need += c[x]; occ += c[x] != 0; }
     u32 total; const u32 excl = block_excl_scan(need, sh, total);
     u32 occTotal; block_excl_scan(occ, sh, occTotal);
     if (threadIdx.x == 0) { shBase = total ? atomicAdd(&counters[5], (u64)total) : 0ull; if (occTotal) atomicAdd(&counters[6], (u64)occTotal); }
@@ -393,16 +407,6 @@ __global__ __launch_bounds__(256) void k_mi_alloc(u64* mi1, u64 TL, const u32* _
             start += c[x];
         }
     }
-}
-__global__ void k_mi_fill(const u64* __restrict__ slots, u64 T, const u32* __restrict__ slot_mh, const u64* __restrict__ mi1, u32* mcur, u64* krec) {
-    const u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x; if (idx >= T) return;
-    const u64 s = slots[idx]; if (s == 0) return;
-    const u32 g = slot_mh[idx];
-    if (g == 0xFFFFFFFFu) return;
-    const u64 v = mi1[g];
-    if (((v >> 32) & 255u) == MI_BIG) return;                       // oversized group: never scanned
-    const u32 pos = atomicAdd(&mcur[g], 1u);
-    krec[(u32)v + pos] = s;
 }
 __global__ void k_lookup(const u64* __restrict__ slots, u64 T, const u32* __restrict__ csr, u64 seed, int h, u64 hi, u64 lo, u64* out, u32 cap) {
     u64 s = table_find(slots, T, hash_key(hi, lo, h, seed));
@@ -1359,37 +1363,32 @@ int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t
     if (d->T >= (1ull << 32)) { err = "table too large for 32-bit slot indices"; return SAGE2OV_ERR_LIMIT; }
     const u32 big_cap = 1u << 20;
     WS(slots_ws, u64, WS_SLOTS, d->T); d->slots = slots_ws;
-    WS(cnt, u32, WS_CNT, d->T);
-    WS(where, u32, WS_WHERE, std::max<u64>(1, 4 * N));
+    WS(where, u64, WS_WHERE, std::max<u64>(1, 4 * N));               // per entry: slot index | rank inside the bucket << 32
     WS(big, u64, WS_BIG, (u64)big_cap * 3);
     WS(csr_ws, u32, WS_CSR, std::max<u64>(1, 4 * N)); d->csr = csr_ws;
     const bool wantMI = !getenv("SAGE2OV_NO_MINIMIZER_INDEX") && (d->h - std::min(d->h, 16) + 1) >= 8;
-    u32* slot_mh = nullptr; u64* mi1 = nullptr; u32 *mcnt = nullptr, *mcur = nullptr; u64 TL = 0;
+    u64* slot_g = nullptr; u64* mi1 = nullptr; u64* krec = nullptr; u64 TL = 0;
     if (wantMI) {
         TL = 1024; while (TL < d->T / 4) TL <<= 1;                           // >= 2N group slots
-        WS(smh, u32, WS_SLOTMH, d->T); slot_mh = smh;
-        WS(m1, u64, WS_MI1, TL); mi1 = m1; WS(mc_, u32, WS_MICNT, TL); mcnt = mc_; WS(mu_, u32, WS_MICUR, TL); mcur = mu_;
+        WS(smh, u64, WS_SLOTMH, d->T); slot_g = smh;                         // per bucket: group slot | rank inside the group << 32
+        WS(m1, u64, WS_MI1, TL); mi1 = m1;
+        WS(kr_, u64, WS_KREC, 4 * N + MI_SCAN_PAD); krec = kr_;              // one record per distinct key (<= 4N), written by the fill kernel
     }
     HIPCHK(hipEventRecord(d->ev[0], d->stream));
     *rebuilds = 0;
     for (int attempt = 0;; attempt++) {
-        if (getenv("SAGE2OV_DBG_ZERO_KERNEL")) {
-            hipLaunchKernelGGL(k_zero64, dim3(2048), dim3(256), 0, d->stream, d->slots, (u64)d->T);
-            hipLaunchKernelGGL(k_zero64, dim3(2048), dim3(256), 0, d->stream, (u64*)cnt, (u64)(d->T / 2));
-            if (d->T & 1) HIPCHK(hipMemsetAsync(cnt + d->T - 1, 0, sizeof(u32), d->stream));
-        } else {
         HIPCHK(hipMemsetAsync(d->slots, 0, d->T * sizeof(u64), d->stream));
-        HIPCHK(hipMemsetAsync(cnt, 0, d->T * sizeof(u32), d->stream));
-        }
         HIPCHK(hipMemsetAsync(d->d_counters + 8, 0, 8 * sizeof(u64), d->stream));
-        if (wantMI) { HIPCHK(hipMemsetAsync(mi1, 0, TL * sizeof(u64), d->stream)); HIPCHK(hipMemsetAsync(mcnt, 0, TL * sizeof(u32), d->stream)); HIPCHK(hipMemsetAsync(mcur, 0, TL * sizeof(u32), d->stream)); }
+        if (wantMI) HIPCHK(hipMemsetAsync(mi1, 0, TL * sizeof(u64), d->stream));
         const unsigned gE = (unsigned)std::min<u64>(grid_for(4 * N, 256), 256 * 64);
         u64* dbgk = nullptr;
         if (getenv("SAGE2OV_DBG_WHERE")) HIPCHK(hipMalloc(&dbgk, 16 * N * sizeof(u64)));
-        hipLaunchKernelGGL(k_index_count, dim3(gE), dim3(256), 0, d->stream, d->reads, N, d->S, d->h, d->seed, d->slots, d->T, cnt, where, dbgk);
+        hipLaunchKernelGGL(k_index_count, dim3(gE), dim3(256), 0, d->stream, d->reads, N, d->S, d->h, d->seed, d->slots, d->T, where, dbgk,
+                           slot_g, mi1, TL, d->d_counters + 8);
         if (dbgk) { HIPCHK(hipStreamSynchronize(d->stream)); d->dbg_keys.resize(16 * N); HIPCHK(hipMemcpy(d->dbg_keys.data(), dbgk, 16 * N * sizeof(u64), hipMemcpyDeviceToHost)); hipFree(dbgk); }
-        hipLaunchKernelGGL(k_index_alloc, dim3(grid_for(d->T, ALLOC_ITEMS)), dim3(256), 0, d->stream, d->slots, d->T, cnt, d->d_counters + 8, big, big_cap);
-        hipLaunchKernelGGL(k_index_fill, dim3(gE), dim3(256), 0, d->stream, d->reads, N, d->S, d->h, (u32)d->seed, d->slots, cnt, where, d->csr, slot_mh, mi1, TL, mcnt, d->d_counters + 8);
+        hipLaunchKernelGGL(k_index_alloc, dim3(grid_for(d->T, ALLOC_ITEMS)), dim3(256), 0, d->stream, d->slots, d->T, d->d_counters + 8, big, big_cap);
+        if (wantMI) hipLaunchKernelGGL(k_mi_alloc, dim3(grid_for(TL, ALLOC_ITEMS)), dim3(256), 0, d->stream, mi1, TL, d->d_counters + 8);
+        hipLaunchKernelGGL(k_index_fill, dim3(gE), dim3(256), 0, d->stream, N, d->slots, where, d->csr, slot_g, mi1, krec);
         hipLaunchKernelGGL(k_index_sort, dim3(grid_for(d->T, 256)), dim3(256), 0, d->stream, d->slots, d->T, d->csr);
         u64 c[5];
         HIPCHK(hipMemcpyAsync(c, d->d_counters + 8, sizeof c, hipMemcpyDeviceToHost, d->stream));
@@ -1407,10 +1406,7 @@ int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t
     // ---- stage B: minimiser groups over the distinct-key records
     d->mi1 = nullptr; d->krec = nullptr; d->TL = 0;
     if (wantMI && d->n_keys > 0) {
-        WS(krec, u64, WS_KREC, d->n_keys + MI_SCAN_PAD);
         HIPCHK(hipMemsetAsync(krec + d->n_keys, 0, MI_SCAN_PAD * sizeof(u64), d->stream));   // the probe scan may run past the last group: empty records
-        hipLaunchKernelGGL(k_mi_alloc, dim3(grid_for(TL, ALLOC_ITEMS)), dim3(256), 0, d->stream, mi1, TL, mcnt, d->d_counters + 8);
-        hipLaunchKernelGGL(k_mi_fill, dim3(grid_for(d->T, 256)), dim3(256), 0, d->stream, d->slots, d->T, slot_mh, mi1, mcur, krec);
         u64 mc[3];
         HIPCHK(hipMemcpyAsync(mc, d->d_counters + 8 + 5, sizeof mc, hipMemcpyDeviceToHost, d->stream));
         HIPCHK(hipStreamSynchronize(d->stream));
@@ -1420,7 +1416,10 @@ int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t
     HIPCHK(hipEventRecord(d->ev[1], d->stream));
     HIPCHK(hipStreamSynchronize(d->stream));
     float ms = 0; hipEventElapsedTime(&ms, d->ev[0], d->ev[1]); d->tm.index_ms += ms;
-    if (getenv("SAGE2OV_DBG_WHERE")) { d->dbg_where.resize(4 * N); HIPCHK(hipMemcpy(d->dbg_where.data(), where, 4 * N * sizeof(u32), hipMemcpyDeviceToHost)); }
+    if (getenv("SAGE2OV_DBG_WHERE")) {
+        std::vector<u64> w64(4 * N); HIPCHK(hipMemcpy(w64.data(), where, 4 * N * sizeof(u64), hipMemcpyDeviceToHost));
+        d->dbg_where.resize(4 * N); for (u64 x = 0; x < 4 * N; x++) d->dbg_where[x] = (u32)w64[x];
+    }
     *slots_out = d->T; *keys_out = d->n_keys; *csr_out = d->n_csr; *nlong_out = d->n_long;
     return 0;
 }
