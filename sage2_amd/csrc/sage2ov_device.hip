@@ -50,10 +50,10 @@ struct Device {
     std::vector<u32> dbg_where; std::vector<u64> dbg_keys;
     // workspace arena: buffers of the timed path are allocated once and only ever grow (no hipMalloc/hipFree per step)
     struct Buf { void* p = nullptr; size_t cap = 0; };
-    Buf ws[32];
+    Buf ws[48];
 };
 enum { WS_SLOTS, WS_CNT, WS_WHERE, WS_BIG, WS_CSR, WS_SLOW, WS_NEED, WS_DEG, WS_OFFS, WS_CURSOR, WS_KEYS, WS_KEEP, WS_POS, WS_OWNER, WS_FINAL,
-       WS_PARTIAL, WS_IDS, WS_NEAR, WS_HITS, WS_MINH, WS_OCNT, WS_OOFF, WS_OCUR, WS_ORDER, WS_MI1, WS_MICNT, WS_MICUR, WS_KREC, WS_SLOTMH };
+       WS_PARTIAL, WS_IDS, WS_NEAR, WS_HITS, WS_MINH, WS_OCNT, WS_OOFF, WS_OCUR, WS_ORDER, WS_MI1, WS_MICNT, WS_MICUR, WS_KREC, WS_SLOTMH, WS_RA_DEG, WS_RA_OFF, WS_RA_CUR, WS_RA_ENT, WS_RA_RM };
 static void* ws_get(Device* d, int id, size_t bytes) {
     Device::Buf& b = d->ws[id];
     if (b.cap < bytes || !b.p) {
@@ -1263,6 +1263,131 @@ __global__ void k_red_unresolved(u64 N, const uint8_t* __restrict__ status, u32*
 }
 
 // =============================================================================================
+// Reduce phase on the device (economyGraph.cpp:495-707) -- order-independent form, SURVEY A.6.
+// Exact when discovery is symmetric, i.e. when no bucket is long (every S-S overlap is then seen from both
+// sides, contained reads are never in S, and at the time markTransitiveEdge(r) runs in the serial BFS the lists
+// of r and of all its neighbours are complete and unreduced).  The serial replay on the host remains the
+// path for indexes with long buckets and for a handful of unresolved reads.
+//   list[r] (all reads) = both directed entries of every reciprocal-pass candidate + for r in S its own hits;
+//   for r in S: sort (len desc, id desc, type desc) (:853-871), mark (:643-679), drop marked (:681-707);
+//   survivors with to > r replace the candidates owned by r.
+// Entry = len:20 | to:32 | type:2 | position:9 (spare bits of the sort key carry the entry's place in the list).
+// =============================================================================================
+constexpr int RA_CAP = 512;                       // longest list handled on the device (connections <= 300 for S reads)
+constexpr int RA_HT = 1024;
+__device__ __forceinline__ u64 ra_key(u32 to, u32 type, u32 len) { return ((u64)(len & 0xFFFFFu) << 43) | ((u64)to << 11) | ((u64)(type & 3u) << 9); }
+__device__ __forceinline__ u32 ra_to(u64 k) { return (u32)(k >> 11); }
+__device__ __forceinline__ u32 ra_type(u64 k) { return (u32)(k >> 9) & 3u; }
+__device__ __forceinline__ u32 ra_len(u64 k) { return (u32)(k >> 43) & 0xFFFFFu; }
+__global__ void k_ra_degree_c(EdgeCand* cand, u64 n, const uint8_t* __restrict__ status, u32* deg) {
+    u64 x = (u64)blockIdx.x * blockDim.x + threadIdx.x; if (x >= n) return;
+    EdgeCand e = cand[x]; e.type &= 0x7Fu;
+    atomicAdd(&deg[e.from], 1u); atomicAdd(&deg[e.to], 1u);
+    if (status[e.from] == 0) cand[x].type = e.type | 0x80u;            // list of an unresolved read: re-emitted after the reduction
+}
+__global__ void k_ra_degree_h(const Hit* __restrict__ hits, u64 n, u32* deg) {
+    u64 x = (u64)blockIdx.x * blockDim.x + threadIdx.x; if (x >= n) return;
+    atomicAdd(&deg[hits[x].from], 1u);
+}
+__global__ void k_ra_fill_c(const EdgeCand* __restrict__ cand, u64 n, const u64* __restrict__ reads, int S, const u32* __restrict__ offs, u32* cursor, u64* ent) {
+    u64 x = (u64)blockIdx.x * blockDim.x + threadIdx.x; if (x >= n) return;
+    EdgeCand e = cand[x]; e.type &= 0x7Fu;
+    const int Lf = (int)(reads[(u64)e.from * S + S - 1] & 0xFFFF), Lt = (int)(reads[(u64)e.to * S + S - 1] & 0xFFFF);
+    ent[offs[e.from] + atomicAdd(&cursor[e.from], 1u)] = ra_key(e.to, e.type, e.len);
+    ent[offs[e.to] + atomicAdd(&cursor[e.to], 1u)] = ra_key(e.from, flip_type(e.type), (u32)(Lf - (Lt - (int)e.len)));   // the twin (economyGraph.cpp:821)
+}
+__global__ void k_ra_fill_h(const Hit* __restrict__ hits, u64 n, const u32* __restrict__ offs, u32* cursor, u64* ent) {
+    u64 x = (u64)blockIdx.x * blockDim.x + threadIdx.x; if (x >= n) return;
+    const Hit h = hits[x];
+    ent[offs[h.from] + atomicAdd(&cursor[h.from], 1u)] = ra_key(h.to, h.type, (u32)h.len);
+}
+struct RaLds { u64 key[RA_CAP]; u32 ht[RA_HT]; uint8_t mk[RA_HT]; unsigned short slot[RA_CAP]; };
+__device__ __forceinline__ u32 ra_hash(u32 id) { return (id * 2654435761u) >> 22; }     // 10 bits
+// counters: [0] lists longer than RA_CAP (-> host replay), [1] removed entries, [2] survivors with to > r
+__global__ __launch_bounds__(256) void k_ra_mark(const u32* __restrict__ ids, u64 nids, const u32* __restrict__ offs, const u32* __restrict__ deg,
+                                                 const u64* __restrict__ ent, uint8_t* rm, u64* counters) {
+    __shared__ RaLds lds[4];
+    RaLds& L = lds[threadIdx.x >> 6];
+    const u32 lane = lane_id();
+    for (u64 w = (u64)blockIdx.x * 4 + (threadIdx.x >> 6); w < nids; w += (u64)gridDim.x * 4) {
+        const u32 r = ids[w]; const u32 n = deg[r]; const u32 o = offs[r];
+        if (n == 0) continue;
+        if (n > (u32)RA_CAP) { if (lane == 0) atomicAdd(&counters[0], 1ull); continue; }
+        u32 P = 64; while (P < n) P <<= 1;
+        wave_sync();
+        for (u32 x = lane; x < P; x += 64) L.key[x] = x < n ? (ent[o + x] | (u64)x) : 0ull;
+        for (u32 x = lane; x < (u32)RA_HT; x += 64) { L.ht[x] = 0; L.mk[x] = 0; }
+        wave_sync();
+        // bitonic sort, descending: (len, id, type) as in compareEdges (:853-871)
+        for (u32 k = 2; k <= P; k <<= 1)
+            for (u32 j = k >> 1; j > 0; j >>= 1) {
+                for (u32 t = lane; t < P / 2; t += 64) {
+                    const u32 i = ((t / j) * 2 * j) + (t % j), l = i + j;
+                    const u64 a = L.key[i], b = L.key[l];
+                    const bool desc = (i & k) == 0;
+                    if (desc ? (a < b) : (a > b)) { L.key[i] = b; L.key[l] = a; }
+                }
+                wave_sync();
+            }
+        // node table: one mark per neighbour id (several entries may lead to the same read)
+        for (u32 x = lane; x < n; x += 64) {
+            const u32 id = ra_to(L.key[x]); u32 sidx = ra_hash(id);
+            for (;;) {
+                const u32 old = atomicCAS(&L.ht[sidx], 0u, id);
+                if (old == 0 || old == id) break;
+                sidx = (sidx + 1) & (RA_HT - 1);
+            }
+            L.slot[x] = (unsigned short)sidx; L.mk[sidx] = 1;
+        }
+        wave_sync();
+        for (u32 x = 0; x < n; x++) {                                   // markTransitiveEdge (:643-679): sequential over the sorted list
+            const u64 ka = L.key[x];
+            if (L.mk[L.slot[x]] != 1) continue;                         // (wave-uniform)
+            const u32 a = ra_to(ka), t1 = ra_type(ka);
+            const u32 na = deg[a], oa = offs[a];
+            for (u32 y = lane; y < na; y += 64) {
+                const u64 kb = ent[oa + y]; const u32 b = ra_to(kb), t2 = ra_type(kb);
+                const bool compat = ((t1 == 0 || t1 == 2) && (t2 == 0 || t2 == 1)) || ((t1 == 1 || t1 == 3) && (t2 == 2 || t2 == 3));
+                if (!compat) continue;
+                u32 sidx = ra_hash(b);
+                for (;;) {
+                    const u32 v = L.ht[sidx];
+                    if (v == 0) break;
+                    if (v == b) { if (L.mk[sidx] == 1) L.mk[sidx] = 2; break; }
+                    sidx = (sidx + 1) & (RA_HT - 1);
+                }
+            }
+            wave_sync();
+        }
+        u32 nrm = 0, nsv = 0;
+        for (u32 x = lane; x < n; x += 64) {
+            const u64 kx = L.key[x]; const bool gone = L.mk[L.slot[x]] == 2;
+            rm[o + (u32)(kx & 511u)] = gone ? 1 : 0;
+            nrm += gone; nsv += (!gone && ra_to(kx) > r);
+        }
+        for (int dlt = 32; dlt; dlt >>= 1) { nrm += __shfl_xor(nrm, dlt); nsv += __shfl_xor(nsv, dlt); }
+        if (lane == 0) { if (nrm) atomicAdd(&counters[1], (u64)nrm); if (nsv) atomicAdd(&counters[2], (u64)nsv); }
+    }
+}
+__global__ void k_ra_emit(const u32* __restrict__ ids, u64 nids, const u32* __restrict__ offs, const u32* __restrict__ deg, const u64* __restrict__ ent,
+                          const uint8_t* __restrict__ rm, EdgeCand* cand, u64 base, u64 cap, u64* counter) {
+    const u32 lane = lane_id();
+    for (u64 w = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < nids; w += ((u64)gridDim.x * blockDim.x) >> 6) {
+        const u32 r = ids[w]; const u32 n = deg[r], o = offs[r];
+        for (u32 x0 = 0; x0 < n; x0 += 64) {
+            const u32 x = x0 + lane; bool keep = false; u64 k = 0;
+            if (x < n) { k = ent[o + x]; keep = rm[o + x] == 0 && ra_to(k) > r; }
+            const u64 bal = __ballot(keep);
+            if (bal) {
+                u64 b0 = 0; if (lane == 0) b0 = atomicAdd(counter, (u64)__popcll(bal)); b0 = __shfl(b0, 0);
+                const u64 pos = base + b0 + (u64)__popcll(bal & ((1ull << lane) - 1ull));
+                if (keep && pos < cap) { EdgeCand e; e.from = r; e.to = ra_to(k); e.len = ra_len(k); e.type = ra_type(k); cand[pos] = e; }
+            }
+        }
+    }
+}
+
+// =============================================================================================
 // sortEconomyGraph + convertGraph (economyGraph.cpp:896, overlapGraph.cpp:84-111) on the candidate list
 // =============================================================================================
 __global__ void k_conv_degree(const EdgeCand* __restrict__ cand, u64 n, u32* deg) {
@@ -1660,6 +1785,81 @@ int dev_unresolved_hits(Device* d, std::vector<Hit>& hits, uint64_t* n_unresolve
         cap = nh + 1024;
     }
     err = "hit buffer sizing failed"; return SAGE2OV_ERR_INTERNAL;
+}
+
+// Reduce phase on the device (see k_ra_mark).  *done = 0 when the preconditions do not hold (long buckets, too few
+// unresolved reads to be worth it, a list longer than RA_CAP, 32-bit offsets exhausted): the caller then runs the
+// serial replay on the host; nothing but the idempotent 0x80 flags has been changed in that case.
+int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved, uint64_t* n_hits, uint64_t* inserted, uint64_t* removed, int* done, std::string& err) {
+    HIPCHK(hipSetDevice(d->ordinal));
+    *done = 0; *inserted = 0; *removed = 0; *n_hits = 0;
+    const u64 N = d->N;
+    HIPCHK(hipEventRecord(d->ev[0], d->stream));
+    // unresolved reads (status 0), any order
+    u32* ids = nullptr; u64 nun = 0;
+    {
+        u64 cap = 1 << 20;
+        for (int attempt = 0; attempt < 2; attempt++) {
+            WS(buf, u32, WS_IDS, cap); ids = buf;
+            HIPCHK(hipMemsetAsync(d->d_counters + 5, 0, sizeof(u64), d->stream));
+            hipLaunchKernelGGL(k_red_unresolved, dim3(grid_for(N, 256)), dim3(256), 0, d->stream, (u64)N, d->status, buf, cap, d->d_counters + 5);
+            HIPCHK(hipMemcpyAsync(&nun, d->d_counters + 5, sizeof nun, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
+            if (nun <= cap) break;
+            cap = nun;
+        }
+    }
+    *n_unresolved = nun;
+    if (nun == 0) { *done = 1; return 0; }
+    if (d->n_long != 0 || nun < min_unresolved) return 0;
+    // directional hits of the unresolved reads, device resident
+    Hit* dh = nullptr; u64 nh = 0;
+    {
+        u64 cap = std::max<u64>(1 << 16, nun * 80); bool ok = false;
+        for (int attempt = 0; attempt < 4 && !ok; attempt++) {
+            WS(hb, Hit, WS_HITS, cap); dh = hb;
+            HIPCHK(hipMemsetAsync(d->d_counters + 4, 0, sizeof(u64), d->stream));
+            ProbeArgs A = base_args(d); A.lo = 1; A.hi = N + 1; A.hits = dh; A.hits_cap = cap;
+            int rc = launch_probe<1>(d, A, err); if (rc) return rc;
+            HIPCHK(hipMemcpyAsync(&nh, d->d_counters + 4, sizeof nh, hipMemcpyDeviceToHost, d->stream));
+            HIPCHK(hipStreamSynchronize(d->stream));
+            if (nh <= cap) ok = true; else cap = nh + 1024;
+        }
+        if (!ok) { err = "hit buffer sizing failed"; return SAGE2OV_ERR_INTERNAL; }
+    }
+    *n_hits = nh;
+    const u64 nc = d->n_cand;
+    WS(deg, u32, WS_RA_DEG, N + 2); WS(offs, u32, WS_RA_OFF, N + 2); WS(cur, u32, WS_RA_CUR, N + 2);
+    HIPCHK(hipMemsetAsync(deg, 0, (N + 2) * sizeof(u32), d->stream)); HIPCHK(hipMemsetAsync(cur, 0, (N + 2) * sizeof(u32), d->stream));
+    if (nc) hipLaunchKernelGGL(k_ra_degree_c, dim3(grid_for(nc, 256)), dim3(256), 0, d->stream, d->cand, (u64)nc, d->status, deg);
+    if (nh) hipLaunchKernelGGL(k_ra_degree_h, dim3(grid_for(nh, 256)), dim3(256), 0, d->stream, dh, (u64)nh, deg);
+    u64 tot = 0; { int rc = scan_u32(d, deg, N + 2, offs, &tot, err); if (rc) return rc; }
+    if (tot >= (1ull << 32) - 64) return 0;
+    WS(ent, u64, WS_RA_ENT, tot + 1); WS(rm, uint8_t, WS_RA_RM, tot + 1);
+    if (nc) hipLaunchKernelGGL(k_ra_fill_c, dim3(grid_for(nc, 256)), dim3(256), 0, d->stream, d->cand, (u64)nc, d->reads, d->S, offs, cur, ent);
+    if (nh) hipLaunchKernelGGL(k_ra_fill_h, dim3(grid_for(nh, 256)), dim3(256), 0, d->stream, dh, (u64)nh, offs, cur, ent);
+    HIPCHK(hipMemsetAsync(d->d_counters + 8, 0, 4 * sizeof(u64), d->stream));
+    const unsigned gb = (unsigned)std::min<u64>((nun + 3) / 4, 256ull * 16);
+    hipLaunchKernelGGL(k_ra_mark, dim3(gb), dim3(256), 0, d->stream, ids, (u64)nun, offs, deg, ent, rm, d->d_counters + 8);
+    u64 c[3];
+    HIPCHK(hipMemcpyAsync(c, d->d_counters + 8, sizeof c, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
+    HIPCHK(hipGetLastError());
+    if (c[0] != 0) return 0;                                              // a list does not fit the device kernel: serial replay
+    if (d->n_cand + c[2] > d->cand_cap) {
+        EdgeCand* ncand = nullptr; const u64 ncap = d->n_cand + c[2] + 1024;
+        HIPCHK(hipMalloc(&ncand, ncap * sizeof(EdgeCand)));
+        HIPCHK(hipMemcpyAsync(ncand, d->cand, d->n_cand * sizeof(EdgeCand), hipMemcpyDeviceToDevice, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
+        hipFree(d->cand); d->cand = ncand; d->cand_cap = ncap;
+    }
+    HIPCHK(hipMemsetAsync(d->d_counters + 8, 0, sizeof(u64), d->stream));
+    hipLaunchKernelGGL(k_ra_emit, dim3(gb), dim3(256), 0, d->stream, ids, (u64)nun, offs, deg, ent, rm, d->cand, (u64)d->n_cand, (u64)d->cand_cap, d->d_counters + 8);
+    u64 nsv = 0;
+    HIPCHK(hipMemcpyAsync(&nsv, d->d_counters + 8, sizeof nsv, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
+    if (nsv != c[2]) { err = "device reduce: survivor count mismatch"; return SAGE2OV_ERR_INTERNAL; }
+    d->n_cand += nsv;
+    *inserted = nh; *removed = c[1]; *done = 1;
+    HIPCHK(hipEventRecord(d->ev[1], d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
+    float ms = 0; hipEventElapsedTime(&ms, d->ev[0], d->ev[1]); d->tm.hits_ms += ms;
+    return 0;
 }
 
 // candidates that touch an unresolved read or one of its neighbours (their adjacency lists are what

@@ -504,6 +504,21 @@ int sage2ov_overlap_initial(sage2ov_ctx* c) {
 int sage2ov_overlap_reduce(sage2ov_ctx* c) {
     if (!c) return SAGE2OV_ERR_ARG; if (!c->reciprocalDone) return c->fail(SAGE2OV_ERR_ARG, "run the initial pass first");
     auto t0 = std::chrono::steady_clock::now();
+    // Many unresolved reads and no long bucket: the order-independent form runs on the device; the serial
+    // replay below stays the path for long-bucket indexes (A.7) and for a handful of reads.  Both are exact.
+    {
+        const char* ev = getenv("SAGE2OV_DEVICE_REDUCE_MIN");
+        const uint64_t minUn = ev ? strtoull(ev, nullptr, 10) : 4096;
+        uint64_t nun0 = 0, nh0 = 0, ins = 0, rem = 0; int done = 0;
+        if (!getenv("SAGE2OV_HOST_REDUCE")) {
+            int rc0 = dev_reduce_device(c->dev, minUn, &nun0, &nh0, &ins, &rem, &done, c->err); if (rc0) return rc0;
+        }
+        if (done) {
+            c->ostats.unresolved_hits = nh0; c->ostats.edges_inserted = ins; c->ostats.transitive_removed = rem;
+            c->reduce_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            c->reduced = true; c->converted = false; return SAGE2OV_OK;
+        }
+    }
     std::vector<Hit> hits; uint64_t nun = 0;
     int rc = dev_unresolved_hits(c->dev, hits, &nun, c->err); if (rc) return rc;
     c->ostats.unresolved_hits = hits.size(); c->ostats.edges_inserted = 0; c->ostats.transitive_removed = 0;

@@ -61,6 +61,7 @@ int dev_unresolved_hits(Device* d, std::vector<Hit>& hits, uint64_t* n_unresolve
 int dev_download_status(Device* d, std::vector<uint8_t>& status, std::string& err);
 int dev_unresolved_ids(Device* d, std::vector<uint32_t>& ids, std::string& err);          // ascending
 int dev_collect_reduce_edges(Device* d, std::vector<EdgeCand>& out, std::string& err);
+int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved, uint64_t* n_hits, uint64_t* inserted, uint64_t* removed, int* done, std::string& err);
 // append host-computed edge candidates (from the reduce replay) to the device candidate list
 int dev_debug_table(Device* d, uint64_t* out5, std::string& err);
 int dev_debug_where(Device* d, uint32_t* out);
