@@ -1,0 +1,42 @@
+"""Condense rocprofv3 outputs under gpurun_out/ into the tracked files under profiles/.
+
+usage: python tools/make_profile_summary.py <round-tag> <stats_dir> <bench_json> <pmc_dir>...
+  kernel stats csv -> profiles/<tag>_kernel_stats.csv, the bench line of the same profiled run -> profiles/<tag>_bench_under_rocprof.json,
+  PMC passes (one counter group per directory) -> profiles/<tag>_pmc_summary.txt and profiles/probe_traffic.json
+FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB (guide: MI355X_MICROARCH.md, HBM section); the random 64-byte gathers of this
+kernel are not the wide streaming case of the guide's x2 correction, and TCC_EA0_RDREQ x 64 B agrees with FETCH_SIZE as collected.
+"""
+import csv, glob, json, os, shutil, sys, collections
+
+tag, stats_dir, bench_json, pmc_dirs = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4:]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+prof = os.path.join(root, "profiles")
+ks = glob.glob(os.path.join(stats_dir, "**", "*kernel_stats.csv"), recursive=True)[0]
+shutil.copy(ks, os.path.join(prof, f"{tag}_kernel_stats.csv"))
+line = [l for l in open(bench_json) if l.startswith("{")][-1]
+open(os.path.join(prof, f"{tag}_bench_under_rocprof.json"), "w").write(line)
+bench = json.loads(line)
+N = bench["config"]["unique_reads"]
+acc = collections.defaultdict(float); cnt = collections.defaultdict(int)
+for d in pmc_dirs:
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = (r["Kernel_Name"].split("(")[0], r["Counter_Name"]); acc[k] += float(r["Counter_Value"]); cnt[k] += 1
+with open(os.path.join(prof, f"{tag}_pmc_summary.txt"), "w") as o:
+    o.write(f"kernel counter value_per_launch launches per_read(N={N})\n")
+    for (k, c), v in sorted(acc.items(), key=lambda kv: (kv[0][1], kv[0][0])):
+        if not k.startswith(("s2::", "void s2::")):
+            continue
+        n = cnt[(k, c)]; o.write(f"{k} {c} {v / n:.6g} {n} {v / n / N:.3f}\n")
+pk = [k for (k, c) in acc if "k_probe_fast" in k]
+if pk:
+    k = pk[0]
+    f = acc.get((k, "FETCH_SIZE"), 0) / max(cnt.get((k, "FETCH_SIZE"), 1), 1); w = acc.get((k, "WRITE_SIZE"), 0) / max(cnt.get((k, "WRITE_SIZE"), 1), 1)
+    if f:
+        tj = os.path.join(prof, "probe_traffic.json")
+        cur = json.load(open(tj)) if os.path.exists(tj) else {}
+        wl = bench["config"]["workload"].split(" x ")
+        key = f"{wl[0]}x150_k40"
+        cur[key] = {"bytes_per_launch": (f + w) * 1024.0, "fetch_KiB": f, "write_KiB": w, "kernel": k, "source": f"profiles/{tag}_pmc_summary.txt"}
+        json.dump(cur, open(tj, "w"), indent=1)
+print("ok")
