@@ -503,6 +503,7 @@ struct ProbeArgs {
     u64 lo, hi;                    // read id range [lo, hi)
     u64* right; u64* left; u32* conn; u32* cflag;         // MODE 0 outputs
     const uint8_t* status; Hit* hits; u64 hits_cap; u64* counters;   // MODE 1
+    u32* hitcount;                                         // MODE 1, optional: number of hits of every read (written for status-0 reads)
     const u32* ids; u64 n_ids;                             // optional explicit read list (replaces [lo,hi))
     const u64* mi1; u64 TL; const u64* krec;               // minimiser index (may be null)
     u32* slow; u64 slow_cap;                               // fast kernel: reads handed to the sequential kernel (count in counters[6])
@@ -698,6 +699,7 @@ __global__ __launch_bounds__(64 * WPB) void k_probe(ProbeArgs A) {
                 wave_sync();
             }
         }
+        if (MODE == 1 && A.hitcount && lane == 0) A.hitcount[i] = seq;
         if (MODE == 0 && lane == 0) {
             if (ambR || ambL) { rightLen = 0; leftLen = 0; }                                        // economyGraph.cpp:446-450
             A.right[i] = rightId | ((u64)rightO << 40) | ((u64)(rightLen & 0x3FFFFFu) << 42);
@@ -1285,9 +1287,9 @@ __global__ void k_ra_degree_c(EdgeCand* cand, u64 n, const uint8_t* __restrict__
     atomicAdd(&deg[e.from], 1u); atomicAdd(&deg[e.to], 1u);
     if (status[e.from] == 0) cand[x].type = e.type | 0x80u;            // list of an unresolved read: re-emitted after the reduction
 }
-__global__ void k_ra_degree_h(const Hit* __restrict__ hits, u64 n, u32* deg) {
-    u64 x = (u64)blockIdx.x * blockDim.x + threadIdx.x; if (x >= n) return;
-    atomicAdd(&deg[hits[x].from], 1u);
+__global__ void k_ra_degree_h(const u32* __restrict__ hitcount, u64 N, u32* deg) {       // deg[i] = candidate entries + own hits
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; if (i > N) return;
+    deg[i] += hitcount[i];
 }
 __global__ void k_ra_fill_c(const EdgeCand* __restrict__ cand, u64 n, const u64* __restrict__ reads, int S, const u32* __restrict__ offs, u32* cursor, u64* ent) {
     u64 x = (u64)blockIdx.x * blockDim.x + threadIdx.x; if (x >= n) return;
@@ -1296,23 +1298,35 @@ __global__ void k_ra_fill_c(const EdgeCand* __restrict__ cand, u64 n, const u64*
     ent[offs[e.from] + atomicAdd(&cursor[e.from], 1u)] = ra_key(e.to, e.type, e.len);
     ent[offs[e.to] + atomicAdd(&cursor[e.to], 1u)] = ra_key(e.from, flip_type(e.type), (u32)(Lf - (Lt - (int)e.len)));   // the twin (economyGraph.cpp:821)
 }
-__global__ void k_ra_fill_h(const Hit* __restrict__ hits, u64 n, const u32* __restrict__ offs, u32* cursor, u64* ent) {
+__global__ void k_ra_fill_h(const Hit* __restrict__ hits, u64 n, const u32* __restrict__ offs, const u32* __restrict__ deg, const u32* __restrict__ hitcount, u64* ent) {
     u64 x = (u64)blockIdx.x * blockDim.x + threadIdx.x; if (x >= n) return;
-    const Hit h = hits[x];
-    ent[offs[h.from] + atomicAdd(&cursor[h.from], 1u)] = ra_key(h.to, h.type, (u32)h.len);
+    const Hit h = hits[x];                                               // the hits of a read are numbered 0.. by the probe kernel: no cursor
+    ent[offs[h.from] + (deg[h.from] - hitcount[h.from]) + h.seq] = ra_key(h.to, h.type, (u32)h.len);
 }
 struct RaLds { u64 key[RA_CAP]; u32 ht[RA_HT]; uint8_t mk[RA_HT]; unsigned short slot[RA_CAP]; };
 __device__ __forceinline__ u32 ra_hash(u32 id) { return (id * 2654435761u) >> 22; }     // 10 bits
-// counters: [0] lists longer than RA_CAP (-> host replay), [1] removed entries, [2] survivors with to > r
+__device__ __forceinline__ void ra_mark_one(RaLds& L, u64 kb, u32 t1) {
+    const u32 b = ra_to(kb), t2 = ra_type(kb);
+    const bool compat = ((t1 == 0 || t1 == 2) && (t2 == 0 || t2 == 1)) || ((t1 == 1 || t1 == 3) && (t2 == 2 || t2 == 3));
+    if (!compat) return;
+    u32 sidx = ra_hash(b);
+    for (;;) {
+        const u32 v = L.ht[sidx];
+        if (v == 0) break;
+        if (v == b) { if (L.mk[sidx] == 1) L.mk[sidx] = 2; break; }
+        sidx = (sidx + 1) & (RA_HT - 1);
+    }
+}
+// counters: [0] lists longer than RA_CAP (-> host replay), [1] removed entries.  svn[w] = survivors with to > r of the w-th read.
 __global__ __launch_bounds__(256) void k_ra_mark(const u32* __restrict__ ids, u64 nids, const u32* __restrict__ offs, const u32* __restrict__ deg,
-                                                 const u64* __restrict__ ent, uint8_t* rm, u64* counters) {
+                                                 const u64* __restrict__ ent, uint8_t* rm, u32* svn, u64* counters) {
     __shared__ RaLds lds[4];
     RaLds& L = lds[threadIdx.x >> 6];
     const u32 lane = lane_id();
     for (u64 w = (u64)blockIdx.x * 4 + (threadIdx.x >> 6); w < nids; w += (u64)gridDim.x * 4) {
         const u32 r = ids[w]; const u32 n = deg[r]; const u32 o = offs[r];
-        if (n == 0) continue;
-        if (n > (u32)RA_CAP) { if (lane == 0) atomicAdd(&counters[0], 1ull); continue; }
+        if (n == 0) { if (lane == 0) svn[w] = 0; continue; }
+        if (n > (u32)RA_CAP) { if (lane == 0) { svn[w] = 0; atomicAdd(&counters[0], 1ull); } continue; }
         u32 P = 64; while (P < n) P <<= 1;
         wave_sync();
         for (u32 x = lane; x < P; x += 64) L.key[x] = x < n ? (ent[o + x] | (u64)x) : 0ull;
@@ -1340,24 +1354,24 @@ __global__ __launch_bounds__(256) void k_ra_mark(const u32* __restrict__ ids, u6
             L.slot[x] = (unsigned short)sidx; L.mk[sidx] = 1;
         }
         wave_sync();
-        for (u32 x = 0; x < n; x++) {                                   // markTransitiveEdge (:643-679): sequential over the sorted list
-            const u64 ka = L.key[x];
-            if (L.mk[L.slot[x]] != 1) continue;                         // (wave-uniform)
-            const u32 a = ra_to(ka), t1 = ra_type(ka);
-            const u32 na = deg[a], oa = offs[a];
-            for (u32 y = lane; y < na; y += 64) {
-                const u64 kb = ent[oa + y]; const u32 b = ra_to(kb), t2 = ra_type(kb);
-                const bool compat = ((t1 == 0 || t1 == 2) && (t2 == 0 || t2 == 1)) || ((t1 == 1 || t1 == 3) && (t2 == 2 || t2 == 3));
-                if (!compat) continue;
-                u32 sidx = ra_hash(b);
-                for (;;) {
-                    const u32 v = L.ht[sidx];
-                    if (v == 0) break;
-                    if (v == b) { if (L.mk[sidx] == 1) L.mk[sidx] = 2; break; }
-                    sidx = (sidx + 1) & (RA_HT - 1);
-                }
+        // markTransitiveEdge (:643-679): sequential over the sorted list; the neighbours' lists are fetched eight at a time
+        // (first 64 entries of each, one per lane), so the loop pays one memory round trip per eight neighbours
+        for (u32 x0 = 0; x0 < n; x0 += 8) {
+            u32 na[8], oa[8]; u64 kb[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const u32 a = x0 + u < n ? ra_to(L.key[x0 + u]) : 0u; na[u] = x0 + u < n ? deg[a] : 0u; oa[u] = offs[a]; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) kb[u] = ent[oa[u] + (lane < na[u] ? lane : 0u)];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const u32 x = x0 + u;
+                if (x >= n) break;
+                if (L.mk[L.slot[x]] != 1) continue;                         // (wave-uniform)
+                const u32 t1 = ra_type(L.key[x]);
+                if (lane < na[u]) ra_mark_one(L, kb[u], t1);
+                for (u32 y = lane + 64; y < na[u]; y += 64) ra_mark_one(L, ent[oa[u] + y], t1);
+                wave_sync();
             }
-            wave_sync();
         }
         u32 nrm = 0, nsv = 0;
         for (u32 x = lane; x < n; x += 64) {
@@ -1366,23 +1380,22 @@ __global__ __launch_bounds__(256) void k_ra_mark(const u32* __restrict__ ids, u6
             nrm += gone; nsv += (!gone && ra_to(kx) > r);
         }
         for (int dlt = 32; dlt; dlt >>= 1) { nrm += __shfl_xor(nrm, dlt); nsv += __shfl_xor(nsv, dlt); }
-        if (lane == 0) { if (nrm) atomicAdd(&counters[1], (u64)nrm); if (nsv) atomicAdd(&counters[2], (u64)nsv); }
+        if (lane == 0) { svn[w] = nsv; if (nrm) atomicAdd(&counters[1], (u64)nrm); }
     }
 }
 __global__ void k_ra_emit(const u32* __restrict__ ids, u64 nids, const u32* __restrict__ offs, const u32* __restrict__ deg, const u64* __restrict__ ent,
-                          const uint8_t* __restrict__ rm, EdgeCand* cand, u64 base, u64 cap, u64* counter) {
+                          const uint8_t* __restrict__ rm, const u32* __restrict__ svoff, EdgeCand* cand, u64 base, u64 cap) {
     const u32 lane = lane_id();
     for (u64 w = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < nids; w += ((u64)gridDim.x * blockDim.x) >> 6) {
         const u32 r = ids[w]; const u32 n = deg[r], o = offs[r];
+        u64 pos0 = base + svoff[w];
         for (u32 x0 = 0; x0 < n; x0 += 64) {
             const u32 x = x0 + lane; bool keep = false; u64 k = 0;
             if (x < n) { k = ent[o + x]; keep = rm[o + x] == 0 && ra_to(k) > r; }
             const u64 bal = __ballot(keep);
-            if (bal) {
-                u64 b0 = 0; if (lane == 0) b0 = atomicAdd(counter, (u64)__popcll(bal)); b0 = __shfl(b0, 0);
-                const u64 pos = base + b0 + (u64)__popcll(bal & ((1ull << lane) - 1ull));
-                if (keep && pos < cap) { EdgeCand e; e.from = r; e.to = ra_to(k); e.len = ra_len(k); e.type = ra_type(k); cand[pos] = e; }
-            }
+            const u64 pos = pos0 + (u64)__popcll(bal & ((1ull << lane) - 1ull));
+            if (keep && pos < cap) { EdgeCand e; e.from = r; e.to = ra_to(k); e.len = ra_len(k); e.type = ra_type(k); cand[pos] = e; }
+            pos0 += (u64)__popcll(bal);
         }
     }
 }
@@ -1813,12 +1826,14 @@ int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved
     if (d->n_long != 0 || nun < min_unresolved) return 0;
     // directional hits of the unresolved reads, device resident
     Hit* dh = nullptr; u64 nh = 0;
+    WS(hitcount, u32, WS_RA_CUR, N + 2);
+    HIPCHK(hipMemsetAsync(hitcount, 0, (N + 2) * sizeof(u32), d->stream));
     {
         u64 cap = std::max<u64>(1 << 16, nun * 80); bool ok = false;
         for (int attempt = 0; attempt < 4 && !ok; attempt++) {
             WS(hb, Hit, WS_HITS, cap); dh = hb;
             HIPCHK(hipMemsetAsync(d->d_counters + 4, 0, sizeof(u64), d->stream));
-            ProbeArgs A = base_args(d); A.lo = 1; A.hi = N + 1; A.hits = dh; A.hits_cap = cap;
+            ProbeArgs A = base_args(d); A.lo = 1; A.hi = N + 1; A.hits = dh; A.hits_cap = cap; A.hitcount = hitcount;
             int rc = launch_probe<1>(d, A, err); if (rc) return rc;
             HIPCHK(hipMemcpyAsync(&nh, d->d_counters + 4, sizeof nh, hipMemcpyDeviceToHost, d->stream));
             HIPCHK(hipStreamSynchronize(d->stream));
@@ -1828,33 +1843,32 @@ int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved
     }
     *n_hits = nh;
     const u64 nc = d->n_cand;
-    WS(deg, u32, WS_RA_DEG, N + 2); WS(offs, u32, WS_RA_OFF, N + 2); WS(cur, u32, WS_RA_CUR, N + 2);
+    WS(deg, u32, WS_RA_DEG, N + 2); WS(offs, u32, WS_RA_OFF, N + 2); WS(cur, u32, WS_CURSOR, N + 2);
     HIPCHK(hipMemsetAsync(deg, 0, (N + 2) * sizeof(u32), d->stream)); HIPCHK(hipMemsetAsync(cur, 0, (N + 2) * sizeof(u32), d->stream));
     if (nc) hipLaunchKernelGGL(k_ra_degree_c, dim3(grid_for(nc, 256)), dim3(256), 0, d->stream, d->cand, (u64)nc, d->status, deg);
-    if (nh) hipLaunchKernelGGL(k_ra_degree_h, dim3(grid_for(nh, 256)), dim3(256), 0, d->stream, dh, (u64)nh, deg);
+    hipLaunchKernelGGL(k_ra_degree_h, dim3(grid_for(N + 1, 256)), dim3(256), 0, d->stream, hitcount, (u64)N, deg);
     u64 tot = 0; { int rc = scan_u32(d, deg, N + 2, offs, &tot, err); if (rc) return rc; }
     if (tot >= (1ull << 32) - 64) return 0;
-    WS(ent, u64, WS_RA_ENT, tot + 1); WS(rm, uint8_t, WS_RA_RM, tot + 1);
+    WS(ent, u64, WS_RA_ENT, tot + 64); WS(rm, uint8_t, WS_RA_RM, tot + 64);
     if (nc) hipLaunchKernelGGL(k_ra_fill_c, dim3(grid_for(nc, 256)), dim3(256), 0, d->stream, d->cand, (u64)nc, d->reads, d->S, offs, cur, ent);
-    if (nh) hipLaunchKernelGGL(k_ra_fill_h, dim3(grid_for(nh, 256)), dim3(256), 0, d->stream, dh, (u64)nh, offs, cur, ent);
+    if (nh) hipLaunchKernelGGL(k_ra_fill_h, dim3(grid_for(nh, 256)), dim3(256), 0, d->stream, dh, (u64)nh, offs, deg, hitcount, ent);
     HIPCHK(hipMemsetAsync(d->d_counters + 8, 0, 4 * sizeof(u64), d->stream));
+    WS(svn, u32, WS_NEED, nun + 2); WS(svoff, u32, WS_OWNER, nun + 2);
     const unsigned gb = (unsigned)std::min<u64>((nun + 3) / 4, 256ull * 16);
-    hipLaunchKernelGGL(k_ra_mark, dim3(gb), dim3(256), 0, d->stream, ids, (u64)nun, offs, deg, ent, rm, d->d_counters + 8);
-    u64 c[3];
+    hipLaunchKernelGGL(k_ra_mark, dim3(gb), dim3(256), 0, d->stream, ids, (u64)nun, offs, deg, ent, rm, svn, d->d_counters + 8);
+    u64 nsv = 0; { int rc = scan_u32(d, svn, nun, svoff, &nsv, err); if (rc) return rc; }
+    u64 c[2];
     HIPCHK(hipMemcpyAsync(c, d->d_counters + 8, sizeof c, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
     HIPCHK(hipGetLastError());
     if (c[0] != 0) return 0;                                              // a list does not fit the device kernel: serial replay
-    if (d->n_cand + c[2] > d->cand_cap) {
-        EdgeCand* ncand = nullptr; const u64 ncap = d->n_cand + c[2] + 1024;
+    if (d->n_cand + nsv > d->cand_cap) {
+        EdgeCand* ncand = nullptr; const u64 ncap = d->n_cand + nsv + 1024;
         HIPCHK(hipMalloc(&ncand, ncap * sizeof(EdgeCand)));
         HIPCHK(hipMemcpyAsync(ncand, d->cand, d->n_cand * sizeof(EdgeCand), hipMemcpyDeviceToDevice, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
         hipFree(d->cand); d->cand = ncand; d->cand_cap = ncap;
     }
-    HIPCHK(hipMemsetAsync(d->d_counters + 8, 0, sizeof(u64), d->stream));
-    hipLaunchKernelGGL(k_ra_emit, dim3(gb), dim3(256), 0, d->stream, ids, (u64)nun, offs, deg, ent, rm, d->cand, (u64)d->n_cand, (u64)d->cand_cap, d->d_counters + 8);
-    u64 nsv = 0;
-    HIPCHK(hipMemcpyAsync(&nsv, d->d_counters + 8, sizeof nsv, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
-    if (nsv != c[2]) { err = "device reduce: survivor count mismatch"; return SAGE2OV_ERR_INTERNAL; }
+    hipLaunchKernelGGL(k_ra_emit, dim3(gb), dim3(256), 0, d->stream, ids, (u64)nun, offs, deg, ent, rm, svoff, d->cand, (u64)d->n_cand, (u64)d->cand_cap);
+    HIPCHK(hipGetLastError());
     d->n_cand += nsv;
     *inserted = nh; *removed = c[1]; *done = 1;
     HIPCHK(hipEventRecord(d->ev[1], d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
