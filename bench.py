@@ -180,7 +180,8 @@ def main():
         ctx.reads_add_synth(p, g)
         ctx.reads_organize()
         st = ctx.reads_stats()
-        log(f"[bench] rank 0: {st.good_reads} good reads -> {st.unique_reads} unique, organised in {time.time() - t0:.1f} s")
+        log(f"[bench] rank 0: {st.good_reads} good reads -> {st.unique_reads} unique, generated + organised in {time.time() - t0:.1f} s "
+            f"(step 1 on the device: {ctx.timings().organize_ms:.1f} ms)")
     if world > 1:
         # rank 0 organised the reads; everybody else imports the HBM image (broadcast over RCCL)
         meta = torch.zeros(6, dtype=torch.int64, device=dev)

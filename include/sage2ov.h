@@ -75,8 +75,10 @@ int sage2ov_reads_add_ascii(sage2ov_ctx* ctx, const char* bases, const uint64_t*
 int sage2ov_reads_add_file(sage2ov_ctx* ctx, const char* path1, const char* path2);
 /* ReadLoader::loadFromList (readLoader.cpp:73): list grammar f1=/f2=/f=, '#' comments. */
 int sage2ov_reads_add_list(sage2ov_ctx* ctx, const char* list_path);
-/* ReadLoader::organizeReads (readLoader.cpp:215): sort by stringCompareInBytes order (utils.cpp:224),
- * unique with frequency (u16 wrap), ids 1..N; then uploads the packed reads to HBM. */
+/* ReadLoader::organizeReads (readLoader.cpp:215) + the orientation choice of insertReadIntoList (readLoader.cpp:195):
+ * canonical orientation, sort by stringCompareInBytes order (utils.cpp:224), unique with frequency (u16 wrap), ids 1..N.
+ * With a GPU context all of it runs on the device (the staged forward reads are uploaded once) and the read store stays
+ * resident in HBM; a device-less context (SAGE2OV_DEVICE_NONE) uses the host organiser. */
 int sage2ov_reads_organize(sage2ov_ctx* ctx);
 int sage2ov_reads_stats(const sage2ov_ctx* ctx, sage2ov_read_stats* out);
 /* class Read fields (readLoader.h:21-30) for ids 1..N, arrays indexed [0..N] (entry 0 unused):
@@ -183,6 +185,7 @@ typedef struct sage2ov_timings {
     double probe_kernel_ms;      /* the dominant kernel alone (HIP events on the context stream) */
     uint64_t probe_kernel_launches;
     uint64_t sequential_reads;   /* reads the fast kernel handed to the sequential state-machine kernel */
+    double organize_ms;          /* step 1 on the device: upload of the staged reads .. organised read store resident (HIP events) */
 } sage2ov_timings;
 int sage2ov_timings_get(const sage2ov_ctx* ctx, sage2ov_timings* out);
 int sage2ov_timings_reset(sage2ov_ctx* ctx);

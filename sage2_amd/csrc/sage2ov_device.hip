@@ -53,7 +53,7 @@ struct Device {
     Buf ws[48];
 };
 enum { WS_SLOTS, WS_CNT, WS_WHERE, WS_BIG, WS_CSR, WS_SLOW, WS_NEED, WS_DEG, WS_OFFS, WS_CURSOR, WS_KEYS, WS_KEEP, WS_POS, WS_OWNER, WS_FINAL,
-       WS_PARTIAL, WS_IDS, WS_NEAR, WS_HITS, WS_MINH, WS_OCNT, WS_OOFF, WS_OCUR, WS_ORDER, WS_MI1, WS_MICNT, WS_MICUR, WS_KREC, WS_SLOTMH, WS_RA_DEG, WS_RA_OFF, WS_RA_CUR, WS_RA_ENT, WS_RA_RM };
+       WS_PARTIAL, WS_IDS, WS_NEAR, WS_HITS, WS_MINH, WS_OCNT, WS_OOFF, WS_OCUR, WS_ORDER, WS_MI1, WS_MICNT, WS_MICUR, WS_KREC, WS_SLOTMH, WS_RA_DEG, WS_RA_OFF, WS_RA_CUR, WS_RA_ENT, WS_RA_RM, WS_ORG_POOL, WS_ORG_OFF, WS_ORG_LEN, WS_ORG_IMG, WS_ORG_K0, WS_ORG_K1, WS_ORG_V0, WS_ORG_V1, WS_ORG_HIST, WS_ORG_HSCAN, WS_ORG_FLAG, WS_ORG_UID, WS_ORG_HEAD };
 static void* ws_get(Device* d, int id, size_t bytes) {
     Device::Buf& b = d->ws[id];
     if (b.cap < bytes || !b.p) {
@@ -218,6 +218,102 @@ __global__ void k_order_fill(const u32* __restrict__ minh, u64 n, u64 lo, int sh
     const u64 x = (u64)blockIdx.x * blockDim.x + threadIdx.x; if (x >= n) return;
     const u32 b = minh[x] >> shift; const u32 p = atomicAdd(&cursor[b], 1u);
     order[offs[b] + p] = (u32)(lo + x);
+}
+
+// =============================================================================================
+// Step 1 on the device (readLoader.cpp:179-260): canonical orientation, sort, unique + frequency, read ids.
+// Input: the good reads as the host staged them (forward strand, 2-bit big-endian words, variable length).
+//   k_org_canon   read < revcomp ? read : revcomp (:195), written as an S-word slot with the length in the low 16 bits of
+//                 the last word: comparing slots word by word IS stringCompareInBytes (utils.cpp:224: bytes, then length)
+//   k_rs_*        stable LSD radix sort of (first word, read index), 8 passes of 8 bits, one wave per 2048-element tile
+//   k_org_ties    runs of equal first words ordered by the remaining words (insertion sort; duplicates cost one compare each)
+//   k_org_heads   first read of every run of equal slots = a unique read; exclusive scan = id - 1; run length = frequency (u16 wrap)
+//   k_org_gather  the HBM read store in id order (slot 0 = zeros)
+// =============================================================================================
+constexpr int RS_TILE = 2048;
+__global__ void k_org_canon(const u64* __restrict__ pool, const u64* __restrict__ off, const unsigned short* __restrict__ len, u64 n, int S, u64* img, u64* key0, u32* val) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; if (i >= n) return;
+    const int L = len[i], nw = (L + 31) / 32; const u64* f = pool + off[i];
+    u64 fw[17], rw[16];
+#pragma unroll 1
+    for (int c = 0; c < 17; c++) fw[c] = c < nw ? f[c] : 0ull;
+    bool useF = false, decided = false;                                  // readLoader.cpp:195 (tie: the reverse complement, same bytes)
+#pragma unroll 1
+    for (int c = 0; c < nw; c++) {
+        const int rem = L - 32 * c; u64 r;
+        if (rem >= 32) r = ~rev2(bits64(fw, 17, 2 * (rem - 32)));
+        else r = (~rev2(fw[0] >> (64 - 2 * rem))) & mask_top(rem);
+        rw[c] = r;
+        if (!decided && fw[c] != r) { useF = fw[c] < r; decided = true; }
+    }
+    u64* o = img + i * S;
+#pragma unroll 1
+    for (int c = 0; c < S; c++) { u64 v = c < nw ? (useF ? fw[c] : rw[c]) : 0ull; if (c == S - 1) v |= (u64)L; o[c] = v; if (c == 0) key0[i] = v; }
+    val[i] = (u32)i;
+}
+__global__ __launch_bounds__(64) void k_rs_hist(const u64* __restrict__ keys, u64 n, int shift, u32* hist, u32 nb) {
+    __shared__ u32 h[256];
+    for (int x = threadIdx.x; x < 256; x += 64) h[x] = 0;
+    __syncthreads();
+    const u64 base = (u64)blockIdx.x * RS_TILE;
+    for (int c = 0; c < RS_TILE; c += 64) { const u64 x = base + c + threadIdx.x; if (x < n) atomicAdd(&h[(u32)(keys[x] >> shift) & 255u], 1u); }
+    __syncthreads();
+    for (int x = threadIdx.x; x < 256; x += 64) hist[(u64)x * nb + blockIdx.x] = h[x];
+}
+__global__ __launch_bounds__(64) void k_rs_scatter(const u64* __restrict__ keys, const u32* __restrict__ vals, u64 n, int shift, const u32* __restrict__ hscan, u32 nb,
+                                                  u64* keysOut, u32* valsOut) {
+    __shared__ u32 cnt[256];
+    const u32 lane = threadIdx.x;
+    for (int x = lane; x < 256; x += 64) cnt[x] = hscan[(u64)x * nb + blockIdx.x];
+    wave_sync();
+    const u64 base = (u64)blockIdx.x * RS_TILE;
+    for (int c = 0; c < RS_TILE; c += 64) {
+        const u64 x = base + c + lane; const bool valid = x < n;
+        const u64 k = valid ? keys[x] : 0ull; const u32 v = valid ? vals[x] : 0u;
+        const u32 dgt = (u32)(k >> shift) & 255u;
+        u64 peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; b++) { const u64 m = __ballot((dgt >> b) & 1u); peers &= ((dgt >> b) & 1u) ? m : ~m; }
+        const u32 rank = (u32)__popcll(peers & ((1ull << lane) - 1ull));
+        const u32 old = cnt[dgt];
+        wave_sync();
+        if (valid && rank == 0) cnt[dgt] = old + (u32)__popcll(peers);
+        wave_sync();
+        if (valid) { keysOut[old + rank] = k; valsOut[old + rank] = v; }
+    }
+}
+__device__ __forceinline__ int org_cmp(const u64* __restrict__ img, int S, u32 a, u32 b) {          // words 1.. (word 0 is known equal)
+    const u64 *pa = img + (u64)a * S, *pb = img + (u64)b * S;
+    for (int c = 1; c < S; c++) { const u64 x = pa[c], y = pb[c]; if (x != y) return x < y ? -1 : 1; }
+    return 0;
+}
+__global__ void k_org_ties(const u64* __restrict__ keys, u32* vals, u64 n, const u64* __restrict__ img, int S) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; if (i >= n) return;
+    const u64 k = keys[i];
+    if (i > 0 && keys[i - 1] == k) return;                               // not the first of its run
+    u64 e = i + 1; while (e < n && keys[e] == k) e++;
+    for (u64 x = i + 1; x < e; x++) {
+        const u32 v = vals[x]; u64 j = x;
+        while (j > i && org_cmp(img, S, vals[j - 1], v) > 0) { vals[j] = vals[j - 1]; j--; }
+        vals[j] = v;
+    }
+}
+__global__ void k_org_heads(const u64* __restrict__ keys, const u32* __restrict__ vals, u64 n, const u64* __restrict__ img, int S, u32* flag) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; if (i >= n) return;
+    flag[i] = (i == 0 || keys[i - 1] != keys[i] || org_cmp(img, S, vals[i - 1], vals[i]) != 0) ? 1u : 0u;
+}
+__global__ void k_org_headpos(const u32* __restrict__ flag, const u32* __restrict__ uid, u64 n, u32* headPos, u64 N) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && flag[i]) headPos[uid[i]] = (u32)i;
+    if (i == 0) headPos[N] = (u32)n;
+}
+__global__ void k_org_gather(const u32* __restrict__ vals, const u32* __restrict__ headPos, u64 N, const u64* __restrict__ img, int S, u64* reads, unsigned short* freq) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 id = t / S + 1; const int c = (int)(t % S);
+    if (id > N) return;
+    const u32 hp = headPos[id - 1];
+    reads[id * S + c] = img[(u64)vals[hp] * S + c];
+    if (c == 0) freq[id] = (unsigned short)(headPos[id] - hp);          // u16 wrap like the reference (readLoader.cpp:232)
 }
 
 // =============================================================================================
@@ -1491,6 +1587,69 @@ int dev_upload_reads(Device* d, const uint64_t* words, uint64_t N, int S, int ma
     d->cand_cap = 2 * N + 1024;
     HIPCHK(hipMalloc(&d->cand, d->cand_cap * sizeof(EdgeCand)));
     HIPCHK(hipStreamSynchronize(d->stream));
+    return 0;
+}
+
+static int scan_u32(Device* d, const u32* in, u64 n, u32* out, u64* total, std::string& err);
+// Step 1 on the device: see k_org_canon.  On return the read store is resident exactly as after dev_upload_reads, and the
+// host receives the image (for the .reads writer, lengths) and the frequencies.
+int dev_organize_reads(Device* d, const uint64_t* pool, uint64_t pool_words, const uint64_t* off, const uint16_t* len, uint64_t n, int S, int maxL, int k,
+                       uint64_t* N_out, std::vector<uint64_t>& words_out, std::vector<uint16_t>& freq_out, std::string& err) {
+    HIPCHK(hipSetDevice(d->ordinal));
+    if (S != 4 && S != 8 && S != 16) { err = "unsupported words-per-read (read length limit is 504 bases)"; return SAGE2OV_ERR_LIMIT; }
+    if (n >= (1ull << 32) - RS_TILE) { err = "too many reads for the device organiser"; return SAGE2OV_ERR_LIMIT; }
+    hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipEventRecord(e0, d->stream));
+    u64 N = 0;
+    u64* reads = nullptr; unsigned short* dfreq = nullptr;
+    if (n) {
+        WS(dpool, u64, WS_ORG_POOL, pool_words + 17); WS(doff, u64, WS_ORG_OFF, n); WS(dlen, unsigned short, WS_ORG_LEN, n);
+        WS(img, u64, WS_ORG_IMG, n * S); WS(k0, u64, WS_ORG_K0, n); WS(k1, u64, WS_ORG_K1, n); WS(v0, u32, WS_ORG_V0, n); WS(v1, u32, WS_ORG_V1, n);
+        HIPCHK(hipMemcpyAsync(dpool, pool, pool_words * sizeof(u64), hipMemcpyHostToDevice, d->stream));
+        HIPCHK(hipMemsetAsync(dpool + pool_words, 0, 17 * sizeof(u64), d->stream));
+        HIPCHK(hipMemcpyAsync(doff, off, n * sizeof(u64), hipMemcpyHostToDevice, d->stream));
+        HIPCHK(hipMemcpyAsync(dlen, len, n * sizeof(uint16_t), hipMemcpyHostToDevice, d->stream));
+        hipLaunchKernelGGL(k_org_canon, dim3(grid_for(n, 256)), dim3(256), 0, d->stream, dpool, doff, dlen, (u64)n, S, img, k0, v0);
+        const u32 nb = (u32)((n + RS_TILE - 1) / RS_TILE);
+        WS(hist, u32, WS_ORG_HIST, (u64)256 * nb + 2); WS(hscan, u32, WS_ORG_HSCAN, (u64)256 * nb + 2);
+        u64 *ka = k0, *kb = k1; u32 *va = v0, *vb = v1;
+        for (int pass = 0; pass < 8; pass++) {
+            hipLaunchKernelGGL(k_rs_hist, dim3(nb), dim3(64), 0, d->stream, ka, (u64)n, 8 * pass, hist, nb);
+            u64 tot = 0; int rc = scan_u32(d, hist, (u64)256 * nb, hscan, &tot, err); if (rc) return rc;
+            hipLaunchKernelGGL(k_rs_scatter, dim3(nb), dim3(64), 0, d->stream, ka, va, (u64)n, 8 * pass, hscan, nb, kb, vb);
+            std::swap(ka, kb); std::swap(va, vb);
+        }
+        hipLaunchKernelGGL(k_org_ties, dim3(grid_for(n, 256)), dim3(256), 0, d->stream, ka, va, (u64)n, img, S);
+        WS(flag, u32, WS_ORG_FLAG, n + 2); WS(uid, u32, WS_ORG_UID, n + 2);
+        hipLaunchKernelGGL(k_org_heads, dim3(grid_for(n, 256)), dim3(256), 0, d->stream, ka, va, (u64)n, img, S, flag);
+        { int rc = scan_u32(d, flag, n, uid, &N, err); if (rc) return rc; }
+        if (N >= (1ull << 30)) { err = "more than 2^30-1 unique reads per context is not supported yet"; return SAGE2OV_ERR_LIMIT; }
+        WS(headPos, u32, WS_ORG_HEAD, N + 2);
+        hipLaunchKernelGGL(k_org_headpos, dim3(grid_for(n, 256)), dim3(256), 0, d->stream, flag, uid, (u64)n, headPos, (u64)N);
+        HIPCHK(hipMalloc(&reads, (N + 1) * S * sizeof(u64))); HIPCHK(hipMalloc(&dfreq, (N + 1) * sizeof(unsigned short)));
+        HIPCHK(hipMemsetAsync(reads, 0, S * sizeof(u64), d->stream)); HIPCHK(hipMemsetAsync(dfreq, 0, sizeof(unsigned short), d->stream));
+        hipLaunchKernelGGL(k_org_gather, dim3(grid_for(N * S, 256)), dim3(256), 0, d->stream, va, headPos, (u64)N, img, S, reads, dfreq);
+    } else {
+        HIPCHK(hipMalloc(&reads, S * sizeof(u64))); HIPCHK(hipMalloc(&dfreq, sizeof(unsigned short)));
+        HIPCHK(hipMemsetAsync(reads, 0, S * sizeof(u64), d->stream)); HIPCHK(hipMemsetAsync(dfreq, 0, sizeof(unsigned short), d->stream));
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(e1, d->stream));
+    words_out.resize((N + 1) * S); freq_out.resize(N + 1);
+    HIPCHK(hipMemcpyAsync(words_out.data(), reads, (N + 1) * S * sizeof(u64), hipMemcpyDeviceToHost, d->stream));
+    HIPCHK(hipMemcpyAsync(freq_out.data(), dfreq, (N + 1) * sizeof(unsigned short), hipMemcpyDeviceToHost, d->stream));
+    HIPCHK(hipStreamSynchronize(d->stream));
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1); d->tm.organize_ms += ms; hipEventDestroy(e0); hipEventDestroy(e1);
+    hipFree(dfreq);
+    // the organised store becomes the context's read store (same state as after dev_upload_reads)
+    free_reads(d);
+    d->N = N; d->S = S; d->maxL = maxL; d->k = k; d->h = k > 64 ? 64 : k; d->reads = reads;
+    HIPCHK(hipMalloc(&d->right, (N + 1) * sizeof(u64))); HIPCHK(hipMalloc(&d->left, (N + 1) * sizeof(u64)));
+    HIPCHK(hipMalloc(&d->conn, (N + 1) * sizeof(u32))); HIPCHK(hipMalloc(&d->cflag, (N + 1) * sizeof(u32)));
+    HIPCHK(hipMalloc(&d->status, (N + 1)));
+    d->cand_cap = 2 * N + 1024;
+    HIPCHK(hipMalloc(&d->cand, d->cand_cap * sizeof(EdgeCand)));
+    *N_out = N;
     return 0;
 }
 

@@ -85,13 +85,18 @@ inline void stage_codes(sage2ov_ctx* c, const uint8_t* codes, int L, std::vector
     if (nw > 16) { lens.push_back(0xFFFF); off.push_back(pool.size()); good++; bp += L; return; }   // too long: organise reports the limit
     for (int w = 0; w < nw; w++) f[w] = 0;
     for (int i = 0; i < L; i++) { if (codes[i] > 3) return; f[i >> 5] |= (uint64_t)codes[i] << (62 - 2 * (i & 31)); }
-    revcomp_words(f, nw, L, r);
-    bool useF = false;                                     // readLoader.cpp:195: read < revcomp ? read : revcomp
-    for (int w = 0; w < nw; w++) { if (f[w] != r[w]) { useF = f[w] < r[w]; break; } }
-    const uint64_t* src = useF ? f : r;
+    // the forward strand is staged; the canonical orientation (readLoader.cpp:195) is chosen by the organiser (device or host)
+    (void)r;
     off.push_back(pool.size()); lens.push_back((uint16_t)L);
-    pool.insert(pool.end(), src, src + nw);
+    pool.insert(pool.end(), f, f + nw);
     good++; bp += L;
+}
+inline void canonicalise_words(uint64_t* f, int L) {        // readLoader.cpp:195: read < revcomp ? read : revcomp (tie: revcomp, same bytes)
+    const int nw = (L + 31) / 32; uint64_t r[18];
+    revcomp_words(f, nw, L, r);
+    bool useF = false;
+    for (int w = 0; w < nw; w++) { if (f[w] != r[w]) { useF = f[w] < r[w]; break; } }
+    if (!useF) for (int w = 0; w < nw; w++) f[w] = r[w];
 }
 static uint8_t g_code[256];
 struct CodeInit { CodeInit() { memset(g_code, 255, 256); g_code['A'] = g_code['a'] = 0; g_code['C'] = g_code['c'] = 1; g_code['G'] = g_code['g'] = 2; g_code['T'] = g_code['t'] = 3; } } g_code_init;
@@ -323,6 +328,21 @@ int sage2ov_reads_organize(sage2ov_ctx* c) {                                    
     c->maxL = maxL; c->S = choose_S(std::max(maxL, 1));
     if (c->S > 16 || maxL > 504) return c->fail(SAGE2OV_ERR_LIMIT, "reads longer than 504 bases are not supported");
     if (n >= (1ull << 32)) return c->fail(SAGE2OV_ERR_LIMIT, "too many reads for the host organiser");
+    for (uint64_t i = 0; i < n; i++) if (c->poolLen[i] == 0xFFFF) return c->fail(SAGE2OV_ERR_LIMIT, "reads longer than 504 bases are not supported");
+    if (c->dev && !getenv("SAGE2OV_HOST_ORGANIZE")) {                                 // step 1 on the device: canonical orientation, sort, unique, ids
+        uint64_t N = 0;
+        int rc = dev_organize_reads(c->dev, c->pool.data(), c->pool.size(), c->poolOff.data(), c->poolLen.data(), n, c->S, c->maxL, (int)c->cfg.min_overlap,
+                                    &N, c->words, c->freq, c->err);
+        if (rc) return rc;
+        c->N = N; c->len.assign(N + 1, 0);
+        #pragma omp parallel for
+        for (uint64_t i = 1; i <= N; i++) c->len[i] = (uint16_t)(c->words[i * c->S + c->S - 1] & 0xFFFF);
+        std::vector<uint64_t>().swap(c->pool); std::vector<uint64_t>().swap(c->poolOff); std::vector<uint16_t>().swap(c->poolLen);
+        c->organized = true; c->indexBuilt = c->probed = c->reciprocalDone = c->reduced = c->converted = false;
+        return SAGE2OV_OK;
+    }
+    #pragma omp parallel for
+    for (uint64_t i = 0; i < n; i++) canonicalise_words(&c->pool[c->poolOff[i]], c->poolLen[i]);
     std::vector<uint32_t> ord(n);
     #pragma omp parallel for
     for (uint64_t i = 0; i < n; i++) ord[i] = (uint32_t)i;
@@ -612,7 +632,7 @@ int sage2ov_timings_get(const sage2ov_ctx* c, sage2ov_timings* o) {
     if (!c || !o) return SAGE2OV_ERR_ARG;
     DevTimings t; if (c->dev) dev_timings(c->dev, &t);
     o->index_ms = t.index_ms; o->probe_ms = t.probe_ms; o->reciprocal_ms = t.reciprocal_ms; o->reduce_ms = c->reduce_ms; o->convert_ms = t.convert_ms;
-    o->total_ms = c->total_ms; o->probe_kernel_ms = t.probe_kernel_ms; o->probe_kernel_launches = t.probe_launches; o->sequential_reads = t.slow_reads;
+    o->total_ms = c->total_ms; o->probe_kernel_ms = t.probe_kernel_ms; o->probe_kernel_launches = t.probe_launches; o->sequential_reads = t.slow_reads; o->organize_ms = t.organize_ms;
     return SAGE2OV_OK;
 }
 

@@ -30,7 +30,7 @@ struct EdgeCand { uint32_t from, to; uint32_t len; uint32_t type; };   // from <
 struct Hit { uint32_t from; uint32_t to; int32_t len; uint16_t seq_hi; uint8_t type; uint8_t pad; uint32_t seq; };
 struct FinalEdge { uint32_t from, to, len, len_twin; uint32_t type; };
 
-struct DevTimings { double index_ms = 0, probe_ms = 0, reciprocal_ms = 0, hits_ms = 0, convert_ms = 0, probe_kernel_ms = 0; uint64_t probe_launches = 0, slow_reads = 0; };
+struct DevTimings { double index_ms = 0, probe_ms = 0, reciprocal_ms = 0, hits_ms = 0, convert_ms = 0, probe_kernel_ms = 0, organize_ms = 0; uint64_t probe_launches = 0, slow_reads = 0; };
 
 struct Device;   // opaque, lives in sage2ov_device.hip
 
@@ -61,6 +61,8 @@ int dev_unresolved_hits(Device* d, std::vector<Hit>& hits, uint64_t* n_unresolve
 int dev_download_status(Device* d, std::vector<uint8_t>& status, std::string& err);
 int dev_unresolved_ids(Device* d, std::vector<uint32_t>& ids, std::string& err);          // ascending
 int dev_collect_reduce_edges(Device* d, std::vector<EdgeCand>& out, std::string& err);
+int dev_organize_reads(Device* d, const uint64_t* pool, uint64_t pool_words, const uint64_t* off, const uint16_t* len, uint64_t n, int S, int maxL, int k,
+                       uint64_t* N_out, std::vector<uint64_t>& words_out, std::vector<uint16_t>& freq_out, std::string& err);
 int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved, uint64_t* n_hits, uint64_t* inserted, uint64_t* removed, int* done, std::string& err);
 // append host-computed edge candidates (from the reduce replay) to the device candidate list
 int dev_debug_table(Device* d, uint64_t* out5, std::string& err);

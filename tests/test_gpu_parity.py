@@ -331,3 +331,27 @@ def test_bench_two_ranks_sharing_the_gpu_agree_with_one_rank():
     for key in ("unique_reads", "verified_overlaps", "edges", "edges_crc32", "unresolved_reads"):
         assert r1["config"][key] == r2["config"][key], key
     assert r1["config"]["edges"] > 0
+
+
+@pytest.mark.parametrize("pd,k", [
+    (dict(seed=21, genome_len=60000, n_reads=30000, read_len=150), 40),
+    (dict(seed=22, genome_len=40000, n_reads=30000, read_len=200, read_len_min=60, err_ppm=2000, n_repeat_families=2, repeat_copies=8, repeat_len=500), 21),
+    (dict(seed=23, genome_len=3000, n_reads=20000, read_len=100), 21),          # 670x coverage: long runs of duplicates
+])
+def test_device_organizer_equals_host_organizer(pd, k, monkeypatch):
+    """Step 1 on the device (canonical orientation, radix sort + tie fix-up, unique/frequency, ids) against the host
+    organiser of the same library: identical read store, lengths and frequencies (ids = ranks, readLoader.cpp:215-235)."""
+    bases, off = fx.make_reads(pd)
+    out = {}
+    for mode in ("device", "host"):
+        if mode == "host":
+            monkeypatch.setenv("SAGE2OV_HOST_ORGANIZE", "1")
+        else:
+            monkeypatch.delenv("SAGE2OV_HOST_ORGANIZE", raising=False)
+        g = s2.Context(k, device=0)
+        g.reads_add_ascii(bases, off); g.reads_organize()
+        out[mode] = (g.reads_export(), g.reads_stats().unique_reads, g.timings().organize_ms)
+        g.close()
+    (dp, dl, df), dn, dms = out["device"]; (hp, hl, hf), hn, hms = out["host"]
+    assert dms > 0 and hms == 0, "the device organiser must be the one that ran by default"
+    assert dn == hn and np.array_equal(dl, hl) and np.array_equal(df, hf) and np.array_equal(dp, hp)
