@@ -884,7 +884,10 @@ __device__ __forceinline__ u32 any_mismatch(const u32 (&Y)[NW], const u32* E, in
 #ifndef SAGE2OV_FAST_WPB
 #define SAGE2OV_FAST_WPB 8
 #endif
-template <int S, int NW, int WPL, int WPB>
+// HITS = 1: the same look-up and gather machinery emits the directional hit lists of the status-0 reads for the reduce phase
+// (economyGraph.cpp:591-633) instead of extension records: every candidate is compared directly with this read.
+constexpr u32 HITS_CHUNK = 2048;   // hit slots a wave reserves at a time (one atomic per ~30 reads instead of one per read)
+template <int S, int NW, int WPL, int WPB, int HITS>
 #ifndef SAGE2OV_FAST_WAVES
 #define SAGE2OV_FAST_WAVES 4
 #endif
@@ -920,6 +923,7 @@ __global__ __launch_bounds__(64 * WPB, SAGE2OV_FAST_WAVES) void k_probe_fast(Pro
         const u32 v = A.ids ? A.ids[itc] : (u32)(A.lo + itc);
         return ok ? v : 0u;                                    // 0: nothing to do (slot 0 of the read store is all zero)
     };
+    u64 hBase = 0; u32 hLeft = 0; u64 hTotal = 0;              // HITS: this wave's current chunk of the hit buffer
     const u32 ldw = (lane < (u32)D ? lane : 0u) ^ 1u;
     u32 idCur = id_of(0), idNext = id_of(1);
     u32 wNext = reads32[(u64)idCur * D + ldw];
@@ -931,6 +935,7 @@ __global__ __launch_bounds__(64 * WPB, SAGE2OV_FAST_WAVES) void k_probe_fast(Pro
         idCur = idNext; idNext = id_of(n + 2);
         wNext = reads32[(u64)idCur * D + ldw];
         if (i == 0) continue;
+        if (HITS) { if (A.status[i] != 0) continue; }
         STAMP(0);
         // ---------------------------------------------------------------- stage the read (big-endian dwords) + its reverse complement
         wave_sync();
@@ -1117,6 +1122,7 @@ __global__ __launch_bounds__(64 * WPB, SAGE2OV_FAST_WAVES) void k_probe_fast(Pro
                 myEnt[q] = isCsr ? ce : src; myJ[q] = (int)(cjj & 0x7FFFFFFFu);
                 const u32 r2 = myEnt[q] >> 2; const int t = myEnt[q] & 3;
                 gate[q] = have && (r2 != (u32)i) && ((t == 0 || t == 2) ? (myJ[q] <= L1 - k) : (myJ[q] >= k - h));
+                if (HITS) { const uint8_t st2 = A.status[gate[q] ? r2 : 0u]; gate[q] = gate[q] && st2 == 0; }     // economyGraph.cpp:605 (status[0] is never 0)
             }
 #pragma unroll
             for (int q = 0; q < 2; q++) {
@@ -1135,6 +1141,56 @@ __global__ __launch_bounds__(64 * WPB, SAGE2OV_FAST_WAVES) void k_probe_fast(Pro
                 if (NW == D) Y[q][NW - 1] &= 0xFFFF0000u;
             }
             STAMP(6);
+            if constexpr (HITS != 0) {
+                // ---------------------------------------------------------------- hit lists: direct masked compare of the overlap region
+                bool hit[2] = {false, false}; int hlen[2] = {0, 0}; u32 htype[2] = {0, 0};
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    if (q == 1 && !two) continue;
+                    if (gate[q]) {
+                        const int t = myEnt[q] & 3, j = myJ[q], L2 = myL2[q];
+                        const bool rightSide = (t == 0 || t == 2);
+                        const int span = rightSide ? (L1 - j) : (j + h);
+                        const int n = L2 <= span ? L2 : span;
+                        const int off = L1 - j - h;
+                        const u32* X = (t == 0 || t == 1) ? X0 : X1;
+                        int dd, lo, hi;
+                        if (t == 0) { dd = j; lo = 0; hi = n; } else if (t == 3) { dd = off; lo = 0; hi = n; }
+                        else if (t == 2) { dd = L1 - j - L2; lo = L2 - n; hi = L2; } else { dd = j + h - L2; lo = L2 - n; hi = L2; }
+                        u32 diff = 0;
+#pragma unroll
+                        for (int c = 0; c < NW; c++) diff |= (Y[q][c] ^ get32z(X, D + 2, 2 * (16 * c + dd))) & range_mask32(lo - 16 * c, hi - 16 * c);
+                        hit[q] = diff == 0;                                         // :607-626 (contained-and-equal counts here)
+                        hlen[q] = rightSide ? (L2 - (L1 - j)) : (L2 - j - h);
+                        htype[q] = t == 0 ? 3u : (t == 1 ? 0u : (t == 2 ? 2u : 1u));
+                    }
+                }
+                const u64 b0 = __ballot(hit[0]), b1 = __ballot(hit[1]);
+                const u32 n0 = (u32)__popcll(b0), nh = n0 + (u32)__popcll(b1);
+                if (nh) {
+                    if (nh > hLeft) {                                               // next chunk; the rest of the old one is marked empty
+                        for (u32 x = lane; x < hLeft; x += 64) A.hits[hBase + x].from = 0;
+                        u64 nb_ = 0; if (lane == 0) nb_ = atomicAdd(&A.counters[4], (u64)HITS_CHUNK);
+                        hBase = ((u64)__builtin_amdgcn_readfirstlane((int)(nb_ >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)(u32)nb_);
+                        hLeft = hBase + HITS_CHUNK <= A.hits_cap ? HITS_CHUNK : 0u;     // over capacity: dropped, the host retries with a larger buffer
+                    }
+                    if (nh <= hLeft) {
+                        const u64 lt = (1ull << lane) - 1ull;
+#pragma unroll
+                        for (int q = 0; q < 2; q++) {
+                            if (hit[q]) {
+                                const u32 sq = q == 0 ? (u32)__popcll(b0 & lt) : n0 + (u32)__popcll(b1 & lt);
+                                Hit hh; hh.from = (u32)i; hh.to = myEnt[q] >> 2; hh.len = hlen[q]; hh.seq_hi = 0; hh.type = (uint8_t)htype[q]; hh.pad = 0; hh.seq = sq;
+                                A.hits[hBase + sq] = hh;
+                            }
+                        }
+                        hBase += nh; hLeft -= nh;
+                    }
+                    hTotal += nh;
+                }
+                if (lane == 0) A.hitcount[i] = nh;
+                continue;
+            }
             // ---------------------------------------------------------------- 3. speculation: furthest reach per side
             u32 reachR = ~0u, reachL = ~0u; bool sameLen = true;
 #pragma unroll
@@ -1255,6 +1311,8 @@ __global__ __launch_bounds__(64 * WPB, SAGE2OV_FAST_WAVES) void k_probe_fast(Pro
         STAMP(8);
         if (slowpath) {
             if (lane == 0) { u64 p = atomicAdd(&A.counters[6], 1ull); if (p < A.slow_cap) A.slow[p] = (u32)i; }
+        } else if (HITS) {
+            // (not reached: the hit-list variant leaves the loop body above)
         } else {
             // ---------------------------------------------------------------- 5. extension records
             selR = wave_min_dpp(selR); selL = wave_min_dpp(selL);
@@ -1274,6 +1332,10 @@ __global__ __launch_bounds__(64 * WPB, SAGE2OV_FAST_WAVES) void k_probe_fast(Pro
             if (lane == 0) { A.right[i] = rv; A.left[i] = lv; A.conn[i] = nhits; }
         }
         STAMP(9);
+    }
+    if (HITS) {
+        for (u32 x = lane; x < hLeft; x += 64) A.hits[hBase + x].from = 0;
+        if (lane == 0 && hTotal) atomicAdd(&A.counters[5], hTotal);
     }
 #ifdef SAGE2OV_STAMPS
     if (A.stamps && lane == 0) for (int x = 0; x < 10; x++) atomicAdd(&A.stamps[x], st_acc[x]);
@@ -1397,6 +1459,7 @@ __global__ void k_ra_fill_c(const EdgeCand* __restrict__ cand, u64 n, const u64*
 __global__ void k_ra_fill_h(const Hit* __restrict__ hits, u64 n, const u32* __restrict__ offs, const u32* __restrict__ deg, const u32* __restrict__ hitcount, u64* ent) {
     u64 x = (u64)blockIdx.x * blockDim.x + threadIdx.x; if (x >= n) return;
     const Hit h = hits[x];                                               // the hits of a read are numbered 0.. by the probe kernel: no cursor
+    if (h.from == 0) return;                                             // unused slot of a wave's chunk
     ent[offs[h.from] + (deg[h.from] - hitcount[h.from]) + h.seq] = ra_key(h.to, h.type, (u32)h.len);
 }
 struct RaLds { u64 key[RA_CAP]; u32 ht[RA_HT]; uint8_t mk[RA_HT]; unsigned short slot[RA_CAP]; };
@@ -1776,8 +1839,21 @@ static ProbeArgs base_args(Device* d) {
     return A;
 }
 
-template <int S, int NW, int WPL, int WPB>
-static void launch_fast(Device* d, ProbeArgs& A, unsigned blocks) { hipLaunchKernelGGL((k_probe_fast<S, NW, WPL, WPB>), dim3(blocks), dim3(64 * WPB), 0, d->stream, A); }
+template <int S, int NW, int WPL, int WPB, int HITS = 0>
+static void launch_fast(Device* d, ProbeArgs& A, unsigned blocks) { hipLaunchKernelGGL((k_probe_fast<S, NW, WPL, WPB, HITS>), dim3(blocks), dim3(64 * WPB), 0, d->stream, A); }
+// picks the instantiation for the resident reads; false: the 16-word layout has no fast kernel
+template <int HITS>
+static bool launch_fast_any(Device* d, ProbeArgs& A, unsigned blocks) {
+    constexpr int FW = SAGE2OV_FAST_WPB;      // waves per block: a whole CU's worth works on one locality chunk
+    const int nwinMax = d->maxL - d->h + 1;                               // windows of the longest read
+    if (d->S == 4 && nwinMax <= 128) launch_fast<4, 8, 2, FW, HITS>(d, A, blocks);
+    else if (d->S == 8 && d->maxL <= 160 && nwinMax <= 128) launch_fast<8, 10, 2, FW, HITS>(d, A, blocks);
+    else if (d->S == 8 && d->maxL <= 160) launch_fast<8, 10, 4, FW, HITS>(d, A, blocks);
+    else if (d->S == 8 && nwinMax <= 128) launch_fast<8, 16, 2, FW, HITS>(d, A, blocks);
+    else if (d->S == 8) launch_fast<8, 16, 4, FW, HITS>(d, A, blocks);
+    else return false;
+    return true;
+}
 
 int dev_probe(Device* d, uint64_t lo, uint64_t hi, std::string& err) {
     HIPCHK(hipSetDevice(d->ordinal));
@@ -1802,14 +1878,7 @@ int dev_probe(Device* d, uint64_t lo, uint64_t hi, std::string& err) {
         HIPCHK(hipMemsetAsync(d_stamps, 0, 10 * sizeof(u64), d->stream)); A.stamps = d_stamps;
 #endif
         HIPCHK(hipEventRecord(d->ev[2], d->stream));
-        bool launched = true;
-        constexpr int FW = SAGE2OV_FAST_WPB;      // waves per block: a whole CU's worth works on one locality chunk
-        if (d->S == 4 && nwinMax <= 128) launch_fast<4, 8, 2, FW>(d, A, blocks);
-        else if (d->S == 8 && d->maxL <= 160 && nwinMax <= 128) launch_fast<8, 10, 2, FW>(d, A, blocks);
-        else if (d->S == 8 && d->maxL <= 160) launch_fast<8, 10, 4, FW>(d, A, blocks);
-        else if (d->S == 8 && nwinMax <= 128) launch_fast<8, 16, 2, FW>(d, A, blocks);
-        else if (d->S == 8) launch_fast<8, 16, 4, FW>(d, A, blocks);
-        else launched = false;                                                // 16-word layout: sequential kernel only (for now)
+        const bool launched = launch_fast_any<0>(d, A, blocks);               // false: 16-word layout, sequential kernel only (for now)
         if (!launched) { A.ids = nullptr; A.n_ids = 0; int rc = launch_probe<0>(d, A, err); if (rc) return rc; }
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(d->ev[3], d->stream));
@@ -1983,20 +2052,38 @@ int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved
     *n_unresolved = nun;
     if (nun == 0) { *done = 1; return 0; }
     if (d->n_long != 0 || nun < min_unresolved) return 0;
-    // directional hits of the unresolved reads, device resident
-    Hit* dh = nullptr; u64 nh = 0;
+    // directional hits of the unresolved reads, device resident: the fast kernel in its hit-list form (locality order, minimiser
+    // groups), the sequential kernel for the few reads it hands over (> 128 candidates, ambiguous tags) and for the 16-word layout
+    Hit* dh = nullptr; u64 nh = 0, nslots = 0;
     WS(hitcount, u32, WS_RA_CUR, N + 2);
-    HIPCHK(hipMemsetAsync(hitcount, 0, (N + 2) * sizeof(u32), d->stream));
     {
-        u64 cap = std::max<u64>(1 << 16, nun * 80); bool ok = false;
+        u32* order = nullptr; { int rc = build_locality_order(d, 1, N + 1, &order, err); if (rc) return rc; }
+        WS(slow, u32, WS_SLOW, N + 1);
+        const unsigned blocks = (unsigned)std::min<u64>((N + FAST_CHUNK - 1) / FAST_CHUNK, 256ull * 16);
+        u64 cap = std::max<u64>(1 << 16, nun * 80) + (u64)blocks * SAGE2OV_FAST_WPB * HITS_CHUNK; bool ok = false;
         for (int attempt = 0; attempt < 4 && !ok; attempt++) {
             WS(hb, Hit, WS_HITS, cap); dh = hb;
-            HIPCHK(hipMemsetAsync(d->d_counters + 4, 0, sizeof(u64), d->stream));
+            HIPCHK(hipMemsetAsync(d->d_counters + 4, 0, 3 * sizeof(u64), d->stream));
+            HIPCHK(hipMemsetAsync(hitcount, 0, (N + 2) * sizeof(u32), d->stream));
             ProbeArgs A = base_args(d); A.lo = 1; A.hi = N + 1; A.hits = dh; A.hits_cap = cap; A.hitcount = hitcount;
-            int rc = launch_probe<1>(d, A, err); if (rc) return rc;
-            HIPCHK(hipMemcpyAsync(&nh, d->d_counters + 4, sizeof nh, hipMemcpyDeviceToHost, d->stream));
-            HIPCHK(hipStreamSynchronize(d->stream));
-            if (nh <= cap) ok = true; else cap = nh + 1024;
+            A.ids = order; A.n_ids = N; A.slow = slow; A.slow_cap = N + 1;
+            u64 c3[3] = {0, 0, 0};
+            if (launch_fast_any<1>(d, A, blocks)) {
+                HIPCHK(hipGetLastError());
+                HIPCHK(hipMemcpyAsync(c3, d->d_counters + 4, sizeof c3, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
+                if (c3[0] > cap) { cap = c3[0] + c3[0] / 8 + 1024; continue; }            // some chunk did not fit: everything again
+                if (c3[2]) {                                                                  // handed over: exact sequential kernel, appends behind
+                    ProbeArgs B = base_args(d); B.hits = dh; B.hits_cap = cap; B.hitcount = hitcount; B.ids = slow; B.n_ids = c3[2];
+                    int rc = launch_probe<1>(d, B, err); if (rc) return rc;
+                }
+            } else {
+                A.ids = nullptr; A.n_ids = 0; A.slow = nullptr;
+                int rc = launch_probe<1>(d, A, err); if (rc) return rc;
+            }
+            u64 used = 0;
+            HIPCHK(hipMemcpyAsync(&used, d->d_counters + 4, sizeof used, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
+            if (used > cap) { cap = used + used / 8 + 1024; continue; }
+            nslots = used; nh = c3[1] + (used - c3[0]); ok = true;                           // real hits: fast kernel's count + what the sequential kernel appended
         }
         if (!ok) { err = "hit buffer sizing failed"; return SAGE2OV_ERR_INTERNAL; }
     }
@@ -2010,7 +2097,7 @@ int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved
     if (tot >= (1ull << 32) - 64) return 0;
     WS(ent, u64, WS_RA_ENT, tot + 64); WS(rm, uint8_t, WS_RA_RM, tot + 64);
     if (nc) hipLaunchKernelGGL(k_ra_fill_c, dim3(grid_for(nc, 256)), dim3(256), 0, d->stream, d->cand, (u64)nc, d->reads, d->S, offs, cur, ent);
-    if (nh) hipLaunchKernelGGL(k_ra_fill_h, dim3(grid_for(nh, 256)), dim3(256), 0, d->stream, dh, (u64)nh, offs, deg, hitcount, ent);
+    if (nslots) hipLaunchKernelGGL(k_ra_fill_h, dim3(grid_for(nslots, 256)), dim3(256), 0, d->stream, dh, (u64)nslots, offs, deg, hitcount, ent);
     HIPCHK(hipMemsetAsync(d->d_counters + 8, 0, 4 * sizeof(u64), d->stream));
     WS(svn, u32, WS_NEED, nun + 2); WS(svoff, u32, WS_OWNER, nun + 2);
     const unsigned gb = (unsigned)std::min<u64>((nun + 3) / 4, 256ull * 16);
