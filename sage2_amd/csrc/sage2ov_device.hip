@@ -47,7 +47,6 @@ struct Device {
     // final edges (device resident)
     FinalEdge* final_edges = nullptr; u64 n_final = 0;
     DevTimings tm;
-    std::vector<u32> dbg_where; std::vector<u64> dbg_keys;
     // workspace arena: buffers of the timed path are allocated once and only ever grow (no hipMalloc/hipFree per step)
     struct Buf { void* p = nullptr; size_t cap = 0; };
     Buf ws[48];
@@ -328,23 +327,6 @@ __device__ __forceinline__ void entry_key(const u64* __restrict__ reads, int S, 
     if (t >= 2) rc_key(phi, plo, h, hi, lo); else { hi = phi; lo = plo; }   // hashTable.cpp:96-104
 }
 
-__global__ void k_zero64(u64* p, u64 n) { u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; const u64 st = (u64)gridDim.x * blockDim.x; for (; i < n; i += st) p[i] = 0; }
-template <int VARIANT>
-__global__ void k_index_count_v(const u64* __restrict__ reads, u64 N, int S, int h, u64 seed, u64* slots, u64 T, u32* cnt, u32* where) {
-    u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    const u64 stride = (u64)gridDim.x * blockDim.x;
-    for (; e < 4 * N; e += stride) {
-        u64 hi, lo; entry_key(reads, S, h, (e >> 2) + 1, (int)(e & 3), hi, lo);
-        u64 hv = hash_key(hi, lo, h, seed); const u64 tag = tag_of(hv); u64 idx = home_of(hv, T);
-        for (;;) {
-            u64 old = atomicCAS((u64*)&slots[idx], 0ull, tag << SLOT_TAG_SHIFT);      // always go through the atomic
-            if (old == 0 || (old >> SLOT_TAG_SHIFT) == tag) break;
-            if (++idx == T) idx = 0;
-        }
-        atomicAdd(&cnt[idx], 1u);
-        where[e] = (u32)idx;
-    }
-}
 // During the build a slot is tag:24 | number of entries seen so far:40 and a group word is mtag:24 | number of keys so far:40:
 // claiming and counting are one atomic on one word, and the value the atomic returns is the entry's rank inside its bucket
 // (the key's rank inside its group), so the fill kernel needs no cursors.  k_index_alloc / k_mi_alloc rewrite the words
@@ -363,14 +345,13 @@ __device__ __forceinline__ u64 mi_claim_count(u64* mi1, u64 TL, u32 mh, u32& ran
     }
     return ~0ull;                                                      // table too crowded: the caller gives the minimiser index up
 }
-__global__ void k_index_count(const u64* __restrict__ reads, u64 N, int S, int h, u64 seed, u64* slots, u64 T, u64* where, u64* dbg,
+__global__ void k_index_count(const u64* __restrict__ reads, u64 N, int S, int h, u64 seed, u64* slots, u64 T, u64* where,
                               u64* slot_g, u64* mi1, u64 TL, u64* micounters) {
     u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     const u64 stride = (u64)gridDim.x * blockDim.x;
     for (; e < 4 * N; e += stride) {
         u64 hi, lo; entry_key(reads, S, h, (e >> 2) + 1, (int)(e & 3), hi, lo);
         u64 hv = hash_key(hi, lo, h, seed); const u64 tag = tag_of(hv); u64 idx = home_of(hv, T);
-        if (dbg) { dbg[4 * e] = hi; dbg[4 * e + 1] = lo; dbg[4 * e + 2] = hv; dbg[4 * e + 3] = idx; }
         u64 rank = 0;
         for (;;) {
             u64 s = __hip_atomic_load(&slots[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -928,9 +909,6 @@ __global__ __launch_bounds__(64 * WPB, SAGE2OV_FAST_WAVES) void k_probe_fast(Pro
     u32 idCur = id_of(0), idNext = id_of(1);
     u32 wNext = reads32[(u64)idCur * D + ldw];
     for (u32 n = 0; (blockIdx.x + (u64)(n / PER) * gridDim.x) * FAST_CHUNK < nItems; n++) {
-#ifdef SAGE2OV_LOCKSTEP
-        __syncthreads();       // (measured: lock step costs more than the L2 sharing it buys once the minimiser index is in place)
-#endif
         const u64 i = idCur; const u32 wCur = wNext;
         idCur = idNext; idNext = id_of(n + 2);
         wNext = reads32[(u64)idCur * D + ldw];
@@ -1741,11 +1719,8 @@ int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t
         HIPCHK(hipMemsetAsync(d->d_counters + 8, 0, 8 * sizeof(u64), d->stream));
         if (wantMI) HIPCHK(hipMemsetAsync(mi1, 0, TL * sizeof(u64), d->stream));
         const unsigned gE = (unsigned)std::min<u64>(grid_for(4 * N, 256), 256 * 64);
-        u64* dbgk = nullptr;
-        if (getenv("SAGE2OV_DBG_WHERE")) HIPCHK(hipMalloc(&dbgk, 16 * N * sizeof(u64)));
-        hipLaunchKernelGGL(k_index_count, dim3(gE), dim3(256), 0, d->stream, d->reads, N, d->S, d->h, d->seed, d->slots, d->T, where, dbgk,
+        hipLaunchKernelGGL(k_index_count, dim3(gE), dim3(256), 0, d->stream, d->reads, N, d->S, d->h, d->seed, d->slots, d->T, where,
                            slot_g, mi1, TL, d->d_counters + 8);
-        if (dbgk) { HIPCHK(hipStreamSynchronize(d->stream)); d->dbg_keys.resize(16 * N); HIPCHK(hipMemcpy(d->dbg_keys.data(), dbgk, 16 * N * sizeof(u64), hipMemcpyDeviceToHost)); hipFree(dbgk); }
         hipLaunchKernelGGL(k_index_alloc, dim3(grid_for(d->T, ALLOC_ITEMS)), dim3(256), 0, d->stream, d->slots, d->T, d->d_counters + 8, big, big_cap);
         if (wantMI) hipLaunchKernelGGL(k_mi_alloc, dim3(grid_for(TL, ALLOC_ITEMS)), dim3(256), 0, d->stream, mi1, TL, d->d_counters + 8);
         hipLaunchKernelGGL(k_index_fill, dim3(gE), dim3(256), 0, d->stream, N, d->slots, where, d->csr, slot_g, mi1, krec);
@@ -1776,10 +1751,6 @@ int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t
     HIPCHK(hipEventRecord(d->ev[1], d->stream));
     HIPCHK(hipStreamSynchronize(d->stream));
     float ms = 0; hipEventElapsedTime(&ms, d->ev[0], d->ev[1]); d->tm.index_ms += ms;
-    if (getenv("SAGE2OV_DBG_WHERE")) {
-        std::vector<u64> w64(4 * N); HIPCHK(hipMemcpy(w64.data(), where, 4 * N * sizeof(u64), hipMemcpyDeviceToHost));
-        d->dbg_where.resize(4 * N); for (u64 x = 0; x < 4 * N; x++) d->dbg_where[x] = (u32)w64[x];
-    }
     *slots_out = d->T; *keys_out = d->n_keys; *csr_out = d->n_csr; *nlong_out = d->n_long;
     return 0;
 }
@@ -2011,7 +1982,8 @@ int dev_unresolved_hits(Device* d, std::vector<Hit>& hits, uint64_t* n_unresolve
     for (int attempt = 0; attempt < 4; attempt++) {
         WS(dh, Hit, WS_HITS, cap);
         HIPCHK(hipMemsetAsync(d->d_counters + 4, 0, sizeof(u64), d->stream));
-        ProbeArgs A = base_args(d); A.lo = 1; A.hi = N + 1; A.hits = dh; A.hits_cap = cap;
+        ProbeArgs A = base_args(d); A.hits = dh; A.hits_cap = cap;
+        { WS(idbuf, u32, WS_IDS, nun); A.ids = idbuf; A.n_ids = nun; }    // the list dev_unresolved_ids left on the device: only these reads are probed
         rc = launch_probe<1>(d, A, err); if (rc) return rc;
         u64 nh = 0;
         HIPCHK(hipMemcpyAsync(&nh, d->d_counters + 4, sizeof nh, hipMemcpyDeviceToHost, d->stream));
@@ -2166,8 +2138,6 @@ int dev_debug_table(Device* d, uint64_t* out5, std::string& err) {
     HIPCHK(hipStreamSynchronize(d->stream));
     HIPCHK(hipMemcpy(out5, dk, 5 * sizeof(u64), hipMemcpyDeviceToHost)); hipFree(dk); return 0;
 }
-int dev_debug_where(Device* d, uint32_t* out) { if (d->dbg_where.empty()) return SAGE2OV_ERR_ARG; memcpy(out, d->dbg_where.data(), d->dbg_where.size() * 4); return 0; }
-int dev_debug_countkeys(Device* d, uint64_t* out) { if (d->dbg_keys.empty()) return SAGE2OV_ERR_ARG; memcpy(out, d->dbg_keys.data(), d->dbg_keys.size() * 8); return 0; }
 int dev_debug_keys(Device* d, uint64_t* out, std::string& err) {
     HIPCHK(hipSetDevice(d->ordinal));
     u64* dk = nullptr; HIPCHK(hipMalloc(&dk, 8 * d->N * sizeof(u64)));

@@ -66,8 +66,6 @@ int dev_organize_reads(Device* d, const uint64_t* pool, uint64_t pool_words, con
 int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved, uint64_t* n_hits, uint64_t* inserted, uint64_t* removed, int* done, std::string& err);
 // append host-computed edge candidates (from the reduce replay) to the device candidate list
 int dev_debug_table(Device* d, uint64_t* out5, std::string& err);
-int dev_debug_where(Device* d, uint32_t* out);
-int dev_debug_countkeys(Device* d, uint64_t* out);
 int dev_debug_keys(Device* d, uint64_t* out, std::string& err);
 int dev_debug_all_hits(Device* d, std::vector<Hit>& hits, std::string& err);
 int dev_append_edges(Device* d, const EdgeCand* e, uint64_t n, std::string& err);

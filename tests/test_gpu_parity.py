@@ -355,3 +355,36 @@ def test_device_organizer_equals_host_organizer(pd, k, monkeypatch):
     (dp, dl, df), dn, dms = out["device"]; (hp, hl, hf), hn, hms = out["host"]
     assert dms > 0 and hms == 0, "the device organiser must be the one that ran by default"
     assert dn == hn and np.array_equal(dl, hl) and np.array_equal(df, hf) and np.array_equal(dp, hp)
+
+
+def test_full_size_properties_c2():
+    """BASELINE configs[1] at full size (10 M x 150 bp, k=40, 30 Mb genome, error-free): too big for the oracle, so the result is
+    checked through properties that do not depend on the size:
+      * an error-free single-chromosome genome at 50x: after the transitive reduction the overlap graph is ONE path through all
+        unique reads: N-1 edges, every read has at most one neighbour per end, exactly two reads have a free end;
+      * the canonical list is strictly sorted by (from, to, type) with from < to, lengths are positive and below the read length;
+      * a second run on the same context gives the same bytes (atomics-ordered build, same result)."""
+    import zlib
+    pd = dict(seed=2, genome_len=30_000_000, n_reads=10_000_000, read_len=150)
+    p = fx.synth_params(pd)
+    ctx = s2.Context(40, device=0)
+    ctx.reads_add_synth(p, s2.synth_genome(p)); ctx.reads_organize(); ctx.run_steps23()
+    n = ctx.reads_stats().unique_reads
+    e = ctx.edges()
+    assert len(e) == n - 1
+    f, t, ty = e["from"].astype(np.int64), e["to"].astype(np.int64), e["type"].astype(np.int64)
+    assert np.all(f < t) and np.all(f >= 1) and np.all(t <= n)
+    key = (f << 34) | (t << 2) | ty
+    assert np.all(key[1:] > key[:-1]), "edge list not strictly sorted by (from, to, type)"
+    assert np.all(e["length"] > 0) and np.all(e["length"] < 150) and np.all(e["length_twin"] > 0) and np.all(e["length_twin"] < 150)
+    # which end of each read an edge uses: type bit1 = orientation of the source, bit0 of the destination (SURVEY A.5)
+    src_end = (ty >> 1) & 1                       # 1: leaves `from` through its right end (fwd), 0: through its left end
+    dst_end = 1 - (ty & 1)                        # entering `to` forward = through its left end ... expressed as "end used": 0 left, 1 right
+    use = np.zeros((n + 1, 2), dtype=np.int32)
+    np.add.at(use, (f, src_end), 1); np.add.at(use, (t, dst_end), 1)
+    assert use[1:].max() == 1, "a read has two neighbours on one end after the reduction"
+    assert int((use[1:] == 0).sum()) == 2, "a path has exactly two free ends"
+    crc = zlib.crc32(e.tobytes())
+    ctx.run_steps23()
+    assert zlib.crc32(ctx.edges().tobytes()) == crc
+    ctx.close()
