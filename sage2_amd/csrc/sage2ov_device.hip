@@ -808,13 +808,17 @@ __global__ __launch_bounds__(64 * WPB) void k_probe(ProbeArgs A) {
 // =============================================================================================
 constexpr u64 MI_SCAN_PAD = 272;   // records behind krec[]: the scan of a small group runs up to the wave's largest group (< 255) rounded up to 16
 constexpr int FAST_CAP = 128;
+constexpr int TAIL_OVW = 8;        // dwords per stored overhang (128 bases); longer overhangs go to the sequential kernel
 constexpr int FAST_CHUNK = 64;     // reads per block visit
-template <int S>
+template <int S, int NW, bool TAILED>
 struct FastLds {                   // every string has one zero dword in front (index 0) so that bit positions down to -32 are readable
     u32 xf[2][1 + 2 * S + 2];      // forward, reverse complement as big-endian dwords (+ zero pad behind)
     u32 e[4][1 + 6 * S + 2];       // XR0 = fwd ++ right overhang, XR1 = rc(XR0), XL0 = rc ++ left overhang, XL1 = rc(XL0)
     u32 m[2][1 + 2 * S + 2];       // the two speculated longest-reach reads
-    u32 candJ[FAST_CAP], candSrc[FAST_CAP];
+    u32 candJ[FAST_CAP], candSrc[FAST_CAP];   // (after the entries are resolved the two arrays hold the packed geometry / read id of the verified hits)
+    // inconsistent reads only (the in-kernel state machine): one padded row per lane to cut overhangs out of a candidate, and the
+    // overhang of every verified hit (<= 128 bases) in this read's orientation
+    u32 tslot[TAILED ? FAST_CAP : 1][TAILED ? NW + 3 : 1];   // per candidate slot: the candidate's dwords (zero dword in front, two behind), then its overhang in place
 };
 __device__ __forceinline__ u32 rev2_32(u32 x) { x = __brev(x); return ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1); }
 __device__ __forceinline__ u32 mask_top32(int nb) { return nb >= 16 ? ~0u : (nb <= 0 ? 0u : (~0u << (32 - 2 * nb))); }
@@ -873,8 +877,11 @@ template <int S, int NW, int WPL, int WPB, int HITS>
 #define SAGE2OV_FAST_WAVES 4
 #endif
 __global__ __launch_bounds__(64 * WPB, SAGE2OV_FAST_WAVES) void k_probe_fast(ProbeArgs A) {
-    __shared__ FastLds<S> lds_all[WPB];
-    FastLds<S>& L = lds_all[threadIdx.x >> 6];
+    // the in-kernel state machine for inconsistent reads needs 6.7 KB of LDS per wave at NW = 10; the long-read layouts keep their
+    // occupancy instead and hand such reads to the sequential kernel
+    constexpr bool TAILED = (HITS == 0) && (NW <= 10);
+    __shared__ FastLds<S, NW, TAILED> lds_all[WPB];
+    FastLds<S, NW, TAILED>& L = lds_all[threadIdx.x >> 6];
     const u32 lane = lane_id();
     const int k = A.k, h = A.h;
     constexpr int D = 2 * S;                       // dwords per read slot
@@ -1071,18 +1078,25 @@ __global__ __launch_bounds__(64 * WPB, SAGE2OV_FAST_WAVES) void k_probe_fast(Pro
             const u32 c7 = (u32)(sl[q] >> SLOT_CNT_SHIFT) & 127u;
             cnt[q] = (sl[q] != 0 && c7 != SLOT_CNT_LONG) ? c7 : 0u; pay[q] = (u32)(sl[q] & SLOT_PAY_MASK); mine += cnt[q];
         }
-        const u32 incl = wave_incl_scan_dpp(mine);
-        const u32 total = (u32)__builtin_amdgcn_readlane((int)incl, 63);
+        // candidate slots in window order (j ascending, bucket order inside a window = the order the reference visits them):
+        // window q of lane l is j = 64q + l, so all q = 0 windows come first; two 16-bit prefix sums ride in one DPP scan
+        u32 cbase[WPL]; u32 total = 0;
+#pragma unroll
+        for (int q0 = 0; q0 < WPL; q0 += 2) {
+            const u32 pk = cnt[q0] | ((q0 + 1 < WPL ? cnt[q0 + 1 < WPL ? q0 + 1 : q0] : 0u) << 16);
+            const u32 inc = wave_incl_scan_dpp(pk);
+            const u32 tot = (u32)__builtin_amdgcn_readlane((int)inc, 63);
+            cbase[q0] = total + (inc & 0xFFFFu) - cnt[q0]; total += tot & 0xFFFFu;
+            if (q0 + 1 < WPL) { cbase[q0 + 1 < WPL ? q0 + 1 : q0] = total + (inc >> 16) - cnt[q0 + 1 < WPL ? q0 + 1 : q0]; total += tot >> 16; }
+        }
+        (void)mine;
         if (total > (u32)FAST_CAP) slowpath = true;
         u32 nhits = 0; u32 selR = ~0u, selL = ~0u;
         u32 myEnt[2] = {0, 0}; int myJ[2] = {0, 0}, myL2[2] = {0, 0};
         if (!slowpath) {
-            u32 base = incl - mine;
 #pragma unroll
-            for (int q = 0; q < WPL; q++) {
-                for (u32 e = 0; e < cnt[q]; e++) { L.candJ[base + e] = (u32)jj[q] | (cnt[q] == 1 ? 0u : 0x80000000u); L.candSrc[base + e] = cnt[q] == 1 ? pay[q] : pay[q] + e; }
-                base += cnt[q];
-            }
+            for (int q = 0; q < WPL; q++)
+                for (u32 e = 0; e < cnt[q]; e++) { L.candJ[cbase[q] + e] = (u32)jj[q] | (cnt[q] == 1 ? 0u : 0x80000000u); L.candSrc[cbase[q] + e] = cnt[q] == 1 ? pay[q] : pay[q] + e; }
             wave_sync();
             // ---- gather: entry (CSR for multi-entry buckets), then the 64-byte read slot, two candidates per lane
             u32 Y[2][NW]; bool gate[2];
@@ -1205,9 +1219,10 @@ __global__ __launch_bounds__(64 * WPB, SAGE2OV_FAST_WAVES) void k_probe_fast(Pro
             const int posR = mJ[0], posL = L1 - mJ[1] - h;                                  // offsets in the side's own coordinates
             const int LR = reachR != ~0u ? posR + mL2[0] : 0, LL = reachL != ~0u ? posL + mL2[1] : 0;
             // a speculated read that ends inside this read (containment) or that does not reach its end is left to the sequential kernel
-            if ((reachR != ~0u && LR <= L1) || (reachL != ~0u && LL <= L1)) slowpath = true;
+            bool tail = false;                      // exact state machine over the verified hits, inside this kernel (see the tail below)
+            if ((reachR != ~0u && LR <= L1) || (reachL != ~0u && LL <= L1)) tail = true;
             wave_sync();
-            if (!slowpath) {
+            if (!tail) {
                 // ---- extended strings: lanes 0-31 build the right side, lanes 32-63 the left side, one dword per lane
                 {
                     const int side = lane >> 5, c = (int)(lane & 31);
@@ -1235,12 +1250,12 @@ __global__ __launch_bounds__(64 * WPB, SAGE2OV_FAST_WAVES) void k_probe_fast(Pro
                         const u32* Es = L.e[2 * side] + 1;
                         mbad = ((Es[c] ^ own[c]) & range_mask32(posM - cb, L1 - cb)) != 0 && c < D + 2;
                     } else { wave_sync(); wave_sync(); }
-                    if (__any(mbad)) slowpath = true;
+                    if (__any(mbad)) tail = true;
                 }
                 wave_sync();
             }
             STAMP(7);
-            if (!slowpath) {
+            if (!tail) {
                 // ---------------------------------------------------------------- 4. one whole-length compare per candidate
                 bool bad = false;
                 const int clU = L1 >> 4; const u32 tailU = mask_top32(L1 & 15);
@@ -1283,7 +1298,108 @@ __global__ __launch_bounds__(64 * WPB, SAGE2OV_FAST_WAVES) void k_probe_fast(Pro
                         else selL = min(selL, ((u32)(0x1FF - myJ[q]) << 17) | ((u32)(0x3FF - myL2[q]) << 7) | ci);
                     }
                 }
-                if (__any(bad)) slowpath = true;
+                if (__any(bad)) tail = true;
+            }
+            if (tail && !TAILED) slowpath = true;
+            if constexpr (TAILED) if (tail) {
+                nhits = 0;
+                // ------------------------------------------------------------ tail: some verified hit disagrees with the longest one (read errors,
+                // repeats) or the speculation did not hold.  The reference's state machine (economyGraph.cpp:95-438) is then evaluated as it is
+                // written, hit by hit in window / bucket order, but on data this wave already holds: every candidate is compared directly with
+                // this read, the overhang of every hit goes to LDS, and one step of the machine is a dword-parallel prefix compare of two overhangs.
+                bool thit[2] = {false, false}; bool tooLong = false;
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    if (q == 1 && !two) continue;
+                    const u32 ci = lane + 64 * q;
+                    u32* row = L.tslot[ci] + 1;
+                    L.tslot[ci][0] = 0;
+#pragma unroll
+                    for (int c = 0; c < NW; c++) row[c] = Y[q][c];
+                    row[NW] = 0; row[NW + 1] = 0;
+                    u32 meta = 0; u32 ovd[TAIL_OVW];
+#pragma unroll
+                    for (int c = 0; c < TAIL_OVW; c++) ovd[c] = 0;
+                    if (gate[q]) {
+                        const int t = myEnt[q] & 3, j = myJ[q], L2 = myL2[q];
+                        const bool rightSide = (t == 0 || t == 2);
+                        const int span = rightSide ? (L1 - j) : (j + h);
+                        const bool cont = L2 <= span; const int n = cont ? L2 : span;
+                        const int off = L1 - j - h;
+                        const u32* X = (t == 0 || t == 1) ? X0 : X1;
+                        int dd, lo, hi;
+                        if (t == 0) { dd = j; lo = 0; hi = n; } else if (t == 3) { dd = off; lo = 0; hi = n; }
+                        else if (t == 2) { dd = L1 - j - L2; lo = L2 - n; hi = L2; } else { dd = j + h - L2; lo = L2 - n; hi = L2; }
+                        u32 diff = 0;
+#pragma unroll
+                        for (int c = 0; c < NW; c++) diff |= (Y[q][c] ^ get32z(X, D + 2, 2 * (16 * c + dd))) & range_mask32(lo - 16 * c, hi - 16 * c);
+                        if (diff == 0) {
+                            if (cont) atomicOr(&A.cflag[myEnt[q] >> 2], i > (u64)(myEnt[q] >> 2) ? 1u : 2u);   // economyGraph.cpp:735
+                            else {
+                                const int ov = L2 - n;                                                   // bases of read 2 beyond this read
+                                thit[q] = true; tooLong |= ov > 16 * TAIL_OVW;
+                                meta = 0x80000000u | (rightSide ? 0u : 1u) | ((u32)((t == 2 || t == 3) ? 1 : 0) << 1) | ((u32)L2 << 2) | ((u32)j << 11) | ((u32)(ov & 0xFF) << 20);
+#pragma unroll
+                                for (int c = 0; c < TAIL_OVW; c++) {
+                                    const int rm = ov - 16 * c;
+                                    if (rm > 0) {
+                                        if (t == 0 || t == 3) ovd[c] = get32(row, 2 * (n + 16 * c)) & mask_top32(rm);                 // tail of read 2
+                                        else ovd[c] = rm >= 16 ? ~rev2_32(get32(row, 2 * (rm - 16))) : ((~rev2_32(row[0] >> (32 - 2 * rm))) & mask_top32(rm));   // revcomp of its head
+                                    }
+                                }
+                            }
+                        }
+                    }
+                    // (own slot only: the overhang replaces the candidate's dwords)
+                    if (ci < total || q == 0) {
+                        L.candJ[ci] = meta; L.candSrc[ci] = myEnt[q] >> 2;
+#pragma unroll
+                        for (int c = 0; c < TAIL_OVW; c++) L.tslot[ci][c] = ovd[c];
+                    }
+                }
+                if (__any(tooLong)) slowpath = true;
+                wave_sync();
+                if (!slowpath) {
+                    u32 rightId = 0, rightO = 0, leftId = 0, leftO = 0, rightLen = 0, leftLen = 0;
+                    u32 pRi = 0, pLi = 0, pRL = 0, pLL = 0, pRov = 0, pLov = 0;
+                    bool ambR = false, ambL = false, mAR = false, mAL = false, mFR = false; int curJ = -1;
+                    const u32 nslot = two ? min(total, 128u) : min(total, 64u);
+                    for (u32 x = 0; x < nslot; x++) {
+                        const u32 a = L.candJ[x], r2 = L.candSrc[x];
+                        if (!(a & 0x80000000u)) continue;                               // not a verified hit
+                        nhits++;
+                        const bool isLeft = a & 1u; const u32 o = (a >> 1) & 1u, L2 = (a >> 2) & 0x1FFu, ov = (a >> 20) & 0xFFu; const int jw = (int)((a >> 11) & 0x1FFu);
+                        if (jw != curJ) { curJ = jw; mAR = mAL = mFR = false; }
+                        const u32 pi = isLeft ? pLi : pRi, pov = isLeft ? pLov : pRov;
+                        const int m = (int)min(pov, ov);
+                        const u32 lc = lane < (u32)TAIL_OVW ? lane : 0u;
+                        const bool dif = lane < (u32)TAIL_OVW && ((L.tslot[pi][lc] ^ L.tslot[x][lc]) & mask_top32(m - 16 * (int)lc)) != 0;
+                        const bool cons = !__any(dif);
+                        if (!isLeft) {
+                            if (rightId == 0) { rightId = r2; rightO = o; rightLen = ov; pRi = x; pRL = L2; pRov = ov; mAR = true; mFR = true; }
+                            else if (cons) {
+                                bool upd = false;
+                                if (mAR) { if (L2 > pRL) { if (mFR) { rightId = r2; rightO = o; rightLen = ov; } upd = true; } }
+                                else { upd = true; mAR = true; }
+                                if (upd) { pRi = x; pRL = L2; pRov = ov; }
+                            } else ambR = true;
+                        } else {
+                            if (leftId == 0) { leftId = r2; leftO = o; leftLen = ov; pLi = x; pLL = L2; pLov = ov; mAL = true; }
+                            else if (cons) {
+                                bool upd = false;
+                                if (mAL) { if (L2 > pLL) upd = true; } else { upd = true; mAL = true; }
+                                if (upd) { leftId = r2; leftO = o; leftLen = ov; pLi = x; pLL = L2; pLov = ov; }
+                            } else ambL = true;
+                        }
+                    }
+                    if (ambR || ambL) { rightLen = 0; leftLen = 0; }                                        // economyGraph.cpp:446-450
+                    if (lane == 0) {
+                        A.right[i] = (u64)rightId | ((u64)rightO << 40) | ((u64)(rightLen & 0x3FFFFFu) << 42);
+                        A.left[i] = (u64)leftId | ((u64)leftO << 40) | ((u64)(leftLen & 0x3FFFFFu) << 42);
+                        A.conn[i] = nhits;
+                    }
+                    continue;
+                }
             }
         }
         STAMP(8);
