@@ -1512,8 +1512,14 @@ __global__ void k_red_collect(EdgeCand* cand, u64 n, const uint8_t* __restrict__
     if (status[e.from] == 0) cand[x].type = e.type | 0x80u;    // list of an unresolved read: rewritten by the replay
 }
 __global__ void k_red_unresolved(u64 N, const uint8_t* __restrict__ status, u32* out, u64 cap, u64* counter) {
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x + 1; if (i > N) return;
-    if (status[i] == 0) { u64 p = atomicAdd(counter, 1ull); if (p < cap) out[p] = (u32)i; }
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x + 1;
+    const bool un = i <= N && status[i] == 0;
+    const u64 bal = __ballot(un);                                       // one atomic per wave (most reads are unresolved on noisy data)
+    if (bal == 0) return;
+    u64 base = 0; if (lane_id() == (u32)__builtin_ctzll(bal)) base = atomicAdd(counter, (u64)__popcll(bal));
+    base = __shfl(base, __builtin_ctzll(bal));
+    const u64 p = base + (u64)__popcll(bal & ((1ull << lane_id()) - 1ull));
+    if (un && p < cap) out[p] = (u32)i;
 }
 
 // =============================================================================================
@@ -1608,7 +1614,8 @@ __global__ __launch_bounds__(256) void k_ra_mark(const u32* __restrict__ ids, u6
         }
         wave_sync();
         // markTransitiveEdge (:643-679): sequential over the sorted list; the neighbours' lists are fetched eight at a time
-        // (first 64 entries of each, one per lane), so the loop pays one memory round trip per eight neighbours
+        // (first 64 entries of each, one per lane), so the loop pays one memory round trip per eight neighbours.
+        // (Keeping the list locations in LDS and double-buffering the batches was measured: no gain, the loop is issue-bound.)
         for (u32 x0 = 0; x0 < n; x0 += 8) {
             u32 na[8], oa[8]; u64 kb[8];
 #pragma unroll
