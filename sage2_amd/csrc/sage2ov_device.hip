@@ -346,7 +346,7 @@ __device__ __forceinline__ u64 mi_claim_count(u64* mi1, u64 TL, u32 mh, u32& ran
     return ~0ull;                                                      // table too crowded: the caller gives the minimiser index up
 }
 __global__ void k_index_count(const u64* __restrict__ reads, u64 N, int S, int h, u64 seed, u64* slots, u64 T, u64* where,
-                              u64* slot_g, u64* mi1, u64 TL, u64* micounters) {
+                              u64* whereG, u64* mi1, u64 TL, u64* micounters) {
     u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     const u64 stride = (u64)gridDim.x * blockDim.x;
     for (; e < 4 * N; e += stride) {
@@ -363,12 +363,12 @@ __global__ void k_index_count(const u64* __restrict__ reads, u64 N, int S, int h
             if (++idx == T) idx = 0;
         }
         where[e] = idx | (rank << 32);                                 // (ranks beyond 2^32 cannot occur: 4N < 2^32 entries)
-        if (slot_g && rank == 0) {                                     // one thread per bucket, key still in registers: its minimiser group (stage B)
+        if (whereG && rank == 0) {                                     // one thread per bucket, key still in registers: its minimiser group (stage B)
             u32 k0, k1, k2, k3; key_left_align(hi, lo, h, k0, k1, k2, k3);
             u32 grank = 0;
             const u64 g = mi_claim_count(mi1, TL, minim_hash(key_min_hash(k0, k1, k2, k3, h), (u32)seed), grank);
-            if (g == ~0ull) { atomicAdd(&micounters[7], 1ull); slot_g[idx] = ~0ull; }
-            else slot_g[idx] = g | ((u64)grank << 32);
+            if (g == ~0ull) { atomicAdd(&micounters[7], 1ull); whereG[e] = ~0ull; }
+            else whereG[e] = g | ((u64)grank << 32);                   // read back by the same entry (rank 0) in the fill kernel: a stream, not a gather
         }
     }
 }
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(256) void k_index_alloc(u64* slots, u64 T, u64* cou
     }
 }
 __global__ void k_index_fill(u64 N, u64* slots, const u64* __restrict__ where, u32* csr,
-                             const u64* __restrict__ slot_g, const u64* __restrict__ mi1, u64* krec) {
+                             const u64* __restrict__ whereG, const u64* __restrict__ mi1, u64* krec) {
     u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     const u64 stride = (u64)gridDim.x * blockDim.x;
     for (; e < 4 * N; e += stride) {
@@ -434,8 +434,8 @@ __global__ void k_index_fill(u64 N, u64* slots, const u64* __restrict__ where, u
         const u32 entry = (u32)(((e >> 2) + 1) * 4 + (e & 3));
         if (c7 == 0) { s = (s & (~0ull << SLOT_TAG_SHIFT)) | (1ull << SLOT_CNT_SHIFT) | entry; slots[idx] = s; }   // the only entry: inline
         else csr[(s & SLOT_PAY_MASK) + rank] = entry;
-        if (slot_g && rank == 0) {                                     // one entry per bucket: the bucket's record goes into its minimiser group (stage B)
-            const u64 sg = slot_g[idx];
+        if (whereG && rank == 0) {                                     // one entry per bucket: the bucket's record goes into its minimiser group (stage B)
+            const u64 sg = whereG[e];
             if (sg != ~0ull) {
                 const u64 v = mi1[(u32)sg];
                 if (((v >> 32) & 255u) != MI_BIG) krec[(u32)v + (u32)(sg >> 32)] = s;      // (oversized groups are never scanned)
@@ -1831,7 +1831,7 @@ int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t
     u64* slot_g = nullptr; u64* mi1 = nullptr; u64* krec = nullptr; u64 TL = 0;
     if (wantMI) {
         TL = 1024; while (TL < d->T / 4) TL <<= 1;                           // >= 2N group slots
-        WS(smh, u64, WS_SLOTMH, d->T); slot_g = smh;                         // per bucket: group slot | rank inside the group << 32
+        WS(smh, u64, WS_SLOTMH, std::max<u64>(1, 4 * N)); slot_g = smh;      // per entry (rank-0 entries only): group slot | rank inside the group << 32
         WS(m1, u64, WS_MI1, TL); mi1 = m1;
         WS(kr_, u64, WS_KREC, 4 * N + MI_SCAN_PAD); krec = kr_;              // one record per distinct key (<= 4N), written by the fill kernel
     }
