@@ -1115,6 +1115,9 @@ __global__ __launch_bounds__(64 * WPB, SAGE2OV_FAST_WAVES) void k_probe_fast(Pro
                 const u32 r2 = myEnt[q] >> 2; const int t = myEnt[q] & 3;
                 gate[q] = have && (r2 != (u32)i) && ((t == 0 || t == 2) ? (myJ[q] <= L1 - k) : (myJ[q] >= k - h));
                 if (HITS) { const uint8_t st2 = A.status[gate[q] ? r2 : 0u]; gate[q] = gate[q] && st2 == 0; }     // economyGraph.cpp:605 (status[0] is never 0)
+#ifdef SAGE2OV_TRAFFIC_PROBE      // diagnostic build: no candidate read is fetched (results are meaningless; the PMC traffic of the rest is what is measured)
+                gate[q] = false;
+#endif
             }
 #pragma unroll
             for (int q = 0; q < 2; q++) {

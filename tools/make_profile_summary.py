@@ -32,11 +32,19 @@ pk = [k for (k, c) in acc if "k_probe_fast" in k]
 if pk:
     k = pk[0]
     f = acc.get((k, "FETCH_SIZE"), 0) / max(cnt.get((k, "FETCH_SIZE"), 1), 1); w = acc.get((k, "WRITE_SIZE"), 0) / max(cnt.get((k, "WRITE_SIZE"), 1), 1)
+    # request sizes at the L2's memory side: on gfx950 every read request of this kernel is a 128-byte line (TCC_EA0_RDREQ_128B == TCC_EA0_RDREQ),
+    # which FETCH_SIZE tallies at 64 bytes -- the guide's "double it" case; writes are 32-byte requests and WRITE_SIZE counts them exactly
+    def per_launch(c):
+        return acc.get((k, c), 0) / max(cnt.get((k, c), 1), 1)
+    r128, r64, r32 = per_launch("TCC_EA0_RDREQ_128B_sum"), per_launch("TCC_EA0_RDREQ_64B_sum"), per_launch("TCC_EA0_RDREQ_32B_sum")
+    rd_bytes = (128.0 * r128 + 64.0 * r64 + 32.0 * r32) if r128 else 2.0 * f * 1024.0
     if f:
         tj = os.path.join(prof, "probe_traffic.json")
         cur = json.load(open(tj)) if os.path.exists(tj) else {}
         wl = bench["config"]["workload"].split(" x ")
         key = f"{wl[0]}x150_k40"
-        cur[key] = {"bytes_per_launch": (f + w) * 1024.0, "fetch_KiB": f, "write_KiB": w, "kernel": k, "source": f"profiles/{tag}_pmc_summary.txt"}
+        cur[key] = {"bytes_per_launch": rd_bytes + w * 1024.0, "read_bytes": rd_bytes, "write_bytes": w * 1024.0, "fetch_KiB_as_reported": f, "write_KiB": w,
+                    "read_requests_128B": r128, "kernel": k, "source": f"profiles/{tag}_pmc_summary.txt",
+                    "note": "reads = TCC_EA0_RDREQ_128B x 128 B (all read requests are 128-byte lines; FETCH_SIZE tallies them at 64 B, cf. MI355X_MICROARCH.md HBM section)"}
         json.dump(cur, open(tj, "w"), indent=1)
 print("ok")
