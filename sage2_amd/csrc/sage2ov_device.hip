@@ -39,6 +39,7 @@ struct Device {
     u64 T = 0; u64* slots = nullptr; u32* csr = nullptr; u64 n_csr = 0; u64 seed = 0x5A6E2D0Full;
     u64 n_keys = 0, n_long = 0;
     u64* mi1 = nullptr; u64 TL = 0; u64* krec = nullptr; u64 n_groups = 0;      // minimiser index (fast kernel)
+    int uniL = 0;                                                                // the common read length when all reads have one (else 0): no length gathers
     // per-read results
     u64* right = nullptr; u64* left = nullptr; u32* conn = nullptr; u32* cflag = nullptr; uint8_t* status = nullptr;
     // edge candidates
@@ -1473,16 +1474,18 @@ __global__ void k_recip_cond(u64 N, const u64* __restrict__ right, const u64* __
     }
 }
 __device__ __forceinline__ u32 flip_type(u32 t) { return t == 0 ? 3u : (t == 3 ? 0u : t); }   // utils.cpp:212
-__device__ __forceinline__ EdgeCand make_edge(const u64* reads, int S, u64 u, u64 v, u32 delta, u32 type) {
+// read length: a constant when the data set has a single length (the usual case), else the low 16 bits of the slot's last word
+__device__ __forceinline__ int read_len(const u64* __restrict__ reads, int S, u64 id, int uniL) { return uniL ? uniL : (int)(reads[id * S + S - 1] & 0xFFFF); }
+__device__ __forceinline__ EdgeCand make_edge(const u64* reads, int S, int uniL, u64 u, u64 v, u32 delta, u32 type) {
     EdgeCand e;
     if (u < v) { e.from = (u32)u; e.to = (u32)v; e.len = delta & 0xFFFFFu; e.type = type; }
     else {                                                                                  // the twin lives in the smaller id's list
-        int Lu = (int)(reads[u * S + S - 1] & 0xFFFF), Lv = (int)(reads[v * S + S - 1] & 0xFFFF);
+        const int Lu = read_len(reads, S, u, uniL), Lv = read_len(reads, S, v, uniL);
         e.from = (u32)v; e.to = (u32)u; e.len = (u32)(Lu - (Lv - (int)delta)) & 0xFFFFFu; e.type = flip_type(type);   // economyGraph.cpp:821
     }
     return e;
 }
-__global__ void k_recip_emit(u64 N, const u64* __restrict__ reads, int S, const u64* __restrict__ right, const u64* __restrict__ left,
+__global__ void k_recip_emit(u64 N, const u64* __restrict__ reads, int S, int uniL, const u64* __restrict__ right, const u64* __restrict__ left,
                              const uint8_t* __restrict__ status, EdgeCand* cand, u64 cap, u64* counters, u64 elo, u64 ehi) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x + elo;
     const bool act = i < ehi && i <= N && status[i] == 4;
@@ -1498,8 +1501,8 @@ __global__ void k_recip_emit(u64 N, const u64* __restrict__ reads, int S, const 
     u64 base = 0; if (lane_id() == 0) base = atomicAdd(&counters[0], (u64)(nL + nR));
     base = __shfl(base, 0);
     const u64 lt = (1ull << lane_id()) - 1ull;
-    if (eL) { const u64 p = base + __popcll(bL & lt); if (p < cap) cand[p] = make_edge(reads, S, i, lid, (u32)(l >> 42), ((l >> 40) & 3) == 0 ? 0u : 1u); }
-    if (eR) { const u64 p = base + nL + __popcll(bR & lt); if (p < cap) cand[p] = make_edge(reads, S, i, rid, (u32)(r >> 42), ((r >> 40) & 3) == 0 ? 3u : 2u); }
+    if (eL) { const u64 p = base + __popcll(bL & lt); if (p < cap) cand[p] = make_edge(reads, S, uniL, i, lid, (u32)(l >> 42), ((l >> 40) & 3) == 0 ? 0u : 1u); }
+    if (eR) { const u64 p = base + nL + __popcll(bR & lt); if (p < cap) cand[p] = make_edge(reads, S, uniL, i, rid, (u32)(r >> 42), ((r >> 40) & 3) == 0 ? 3u : 2u); }
 }
 
 // reduce-phase support: the host replay needs the lists of unresolved reads and of their neighbours
@@ -1552,10 +1555,10 @@ __global__ void k_ra_degree_h(const u32* __restrict__ hitcount, u64 N, u32* deg)
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; if (i > N) return;
     deg[i] += hitcount[i];
 }
-__global__ void k_ra_fill_c(const EdgeCand* __restrict__ cand, u64 n, const u64* __restrict__ reads, int S, const u32* __restrict__ offs, u32* cursor, u64* ent) {
+__global__ void k_ra_fill_c(const EdgeCand* __restrict__ cand, u64 n, const u64* __restrict__ reads, int S, int uniL, const u32* __restrict__ offs, u32* cursor, u64* ent) {
     u64 x = (u64)blockIdx.x * blockDim.x + threadIdx.x; if (x >= n) return;
     EdgeCand e = cand[x]; e.type &= 0x7Fu;
-    const int Lf = (int)(reads[(u64)e.from * S + S - 1] & 0xFFFF), Lt = (int)(reads[(u64)e.to * S + S - 1] & 0xFFFF);
+    const int Lf = read_len(reads, S, e.from, uniL), Lt = read_len(reads, S, e.to, uniL);
     ent[offs[e.from] + atomicAdd(&cursor[e.from], 1u)] = ra_key(e.to, e.type, e.len);
     ent[offs[e.to] + atomicAdd(&cursor[e.to], 1u)] = ra_key(e.from, flip_type(e.type), (u32)(Lf - (Lt - (int)e.len)));   // the twin (economyGraph.cpp:821)
 }
@@ -1691,11 +1694,11 @@ __global__ void k_conv_owner(u64 N, const u32* __restrict__ offs, const u32* __r
     u32 d = deg[i]; for (u32 x = 0; x < d; x++) owner[offs[i] + x] = (u32)i;
 }
 __global__ void k_conv_emit(u64 n, const u64* __restrict__ keys, const u32* __restrict__ keep, const u32* __restrict__ pos, const u32* __restrict__ owner,
-                            const u64* __restrict__ reads, int S, FinalEdge* out) {
+                            const u64* __restrict__ reads, int S, int uniL, FinalEdge* out) {
     u64 x = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= n || !keep[x]) return;
     u64 kx = keys[x]; FinalEdge f; f.from = owner[x]; f.to = (u32)(kx >> 22); f.type = (u32)(kx >> 20) & 3u; f.len = (u32)(kx & 0xFFFFFu);
-    u32 Lu = (u32)(reads[(u64)f.from * S + S - 1] & 0xFFFF), Lv = (u32)(reads[(u64)f.to * S + S - 1] & 0xFFFF);
+    const u32 Lu = (u32)read_len(reads, S, f.from, uniL), Lv = (u32)read_len(reads, S, f.to, uniL);
     f.len_twin = Lu - (Lv - f.len);                                                         // overlapGraph.cpp:145-148 (u32 arithmetic)
     out[pos[x]] = f;
 }
@@ -1740,12 +1743,12 @@ int dev_sync(Device* d, std::string& err) { HIPCHK(hipStreamSynchronize(d->strea
 void dev_timings(Device* d, DevTimings* t) { *t = d->tm; }
 void dev_reset_timings(Device* d) { d->tm = DevTimings(); }
 
-int dev_upload_reads(Device* d, const uint64_t* words, uint64_t N, int S, int maxL, int k, std::string& err) {
+int dev_upload_reads(Device* d, const uint64_t* words, uint64_t N, int S, int minL, int maxL, int k, std::string& err) {
     HIPCHK(hipSetDevice(d->ordinal));
     if (S != 4 && S != 8 && S != 16) { err = "unsupported words-per-read (read length limit is 504 bases)"; return SAGE2OV_ERR_LIMIT; }
     if (N >= (1ull << 30)) { err = "more than 2^30-1 unique reads per context is not supported yet"; return SAGE2OV_ERR_LIMIT; }
     free_reads(d);
-    d->N = N; d->S = S; d->maxL = maxL; d->k = k; d->h = k > 64 ? 64 : k;
+    d->N = N; d->S = S; d->maxL = maxL; d->k = k; d->h = k > 64 ? 64 : k; d->uniL = (N && minL == maxL) ? maxL : 0;
     HIPCHK(hipMalloc(&d->reads, (N + 1) * S * sizeof(u64)));
     HIPCHK(hipMemcpyAsync(d->reads, words, (N + 1) * S * sizeof(u64), hipMemcpyHostToDevice, d->stream));
     HIPCHK(hipMalloc(&d->right, (N + 1) * sizeof(u64))); HIPCHK(hipMalloc(&d->left, (N + 1) * sizeof(u64)));
@@ -1760,7 +1763,7 @@ int dev_upload_reads(Device* d, const uint64_t* words, uint64_t N, int S, int ma
 static int scan_u32(Device* d, const u32* in, u64 n, u32* out, u64* total, std::string& err);
 // Step 1 on the device: see k_org_canon.  On return the read store is resident exactly as after dev_upload_reads, and the
 // host receives the image (for the .reads writer, lengths) and the frequencies.
-int dev_organize_reads(Device* d, const uint64_t* pool, uint64_t pool_words, const uint64_t* off, const uint16_t* len, uint64_t n, int S, int maxL, int k,
+int dev_organize_reads(Device* d, const uint64_t* pool, uint64_t pool_words, const uint64_t* off, const uint16_t* len, uint64_t n, int S, int minL, int maxL, int k,
                        uint64_t* N_out, std::vector<uint64_t>& words_out, std::vector<uint16_t>& freq_out, std::string& err) {
     HIPCHK(hipSetDevice(d->ordinal));
     if (S != 4 && S != 8 && S != 16) { err = "unsupported words-per-read (read length limit is 504 bases)"; return SAGE2OV_ERR_LIMIT; }
@@ -1810,7 +1813,7 @@ int dev_organize_reads(Device* d, const uint64_t* pool, uint64_t pool_words, con
     hipFree(dfreq);
     // the organised store becomes the context's read store (same state as after dev_upload_reads)
     free_reads(d);
-    d->N = N; d->S = S; d->maxL = maxL; d->k = k; d->h = k > 64 ? 64 : k; d->reads = reads;
+    d->N = N; d->S = S; d->maxL = maxL; d->k = k; d->h = k > 64 ? 64 : k; d->reads = reads; d->uniL = (N && minL == maxL) ? maxL : 0;
     HIPCHK(hipMalloc(&d->right, (N + 1) * sizeof(u64))); HIPCHK(hipMalloc(&d->left, (N + 1) * sizeof(u64)));
     HIPCHK(hipMalloc(&d->conn, (N + 1) * sizeof(u32))); HIPCHK(hipMalloc(&d->cflag, (N + 1) * sizeof(u32)));
     HIPCHK(hipMalloc(&d->status, (N + 1)));
@@ -2068,7 +2071,7 @@ int dev_reciprocal(Device* d, uint64_t emit_lo, uint64_t emit_hi, uint64_t* n_ov
     HIPCHK(hipMemsetAsync(d->status, 0, N + 1, d->stream));
     hipLaunchKernelGGL(k_recip_cond, dim3(grid_for(N, 256)), dim3(256), 0, d->stream, N, d->right, d->left, d->conn, d->cflag, d->status, d->d_counters);
     if (emit_hi > emit_lo)
-        hipLaunchKernelGGL(k_recip_emit, dim3(grid_for(emit_hi - emit_lo, 256)), dim3(256), 0, d->stream, N, d->reads, d->S, d->right, d->left, d->status, d->cand, d->cand_cap, d->d_counters, (u64)emit_lo, (u64)emit_hi);
+        hipLaunchKernelGGL(k_recip_emit, dim3(grid_for(emit_hi - emit_lo, 256)), dim3(256), 0, d->stream, N, d->reads, d->S, d->uniL, d->right, d->left, d->status, d->cand, d->cand_cap, d->d_counters, (u64)emit_lo, (u64)emit_hi);
     u64 c[8];
     HIPCHK(hipMemcpyAsync(c, d->d_counters, sizeof c, hipMemcpyDeviceToHost, d->stream));
     HIPCHK(hipEventRecord(d->ev[1], d->stream));
@@ -2194,7 +2197,7 @@ int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved
     u64 tot = 0; { int rc = scan_u32(d, deg, N + 2, offs, &tot, err); if (rc) return rc; }
     if (tot >= (1ull << 32) - 64) return 0;
     WS(ent, u64, WS_RA_ENT, tot + 64); WS(rm, uint8_t, WS_RA_RM, tot + 64);
-    if (nc) hipLaunchKernelGGL(k_ra_fill_c, dim3(grid_for(nc, 256)), dim3(256), 0, d->stream, d->cand, (u64)nc, d->reads, d->S, offs, cur, ent);
+    if (nc) hipLaunchKernelGGL(k_ra_fill_c, dim3(grid_for(nc, 256)), dim3(256), 0, d->stream, d->cand, (u64)nc, d->reads, d->S, d->uniL, offs, cur, ent);
     if (nslots) hipLaunchKernelGGL(k_ra_fill_h, dim3(grid_for(nslots, 256)), dim3(256), 0, d->stream, dh, (u64)nslots, offs, deg, hitcount, ent);
     HIPCHK(hipMemsetAsync(d->d_counters + 8, 0, 4 * sizeof(u64), d->stream));
     WS(svn, u32, WS_NEED, nun + 2); WS(svoff, u32, WS_OWNER, nun + 2);
@@ -2343,7 +2346,7 @@ int dev_convert(Device* d, uint64_t* n_final, std::string& err) {
         if (tot) {
             rc = scan_u32(d, keep, tot, pos, &nf, err); if (rc) return rc;
             { WS(fe, FinalEdge, WS_FINAL, std::max<u64>(1, nf)); d->final_edges = fe; }
-            hipLaunchKernelGGL(k_conv_emit, dim3(grid_for(tot, 256)), dim3(256), 0, d->stream, (u64)tot, keys, keep, pos, owner, d->reads, d->S, d->final_edges);
+            hipLaunchKernelGGL(k_conv_emit, dim3(grid_for(tot, 256)), dim3(256), 0, d->stream, (u64)tot, keys, keep, pos, owner, d->reads, d->S, d->uniL, d->final_edges);
         }
         d->n_final = nf;
         HIPCHK(hipStreamSynchronize(d->stream));

@@ -312,7 +312,8 @@ int sage2ov_reads_add_synth(sage2ov_ctx* c, const sage2ov_synth_params* p, const
 
 static int upload(sage2ov_ctx* c) {
     if (!c->dev) { c->organized = true; return SAGE2OV_OK; }      // step-1-only context (SAGE2OV_DEVICE_NONE)
-    int rc = dev_upload_reads(c->dev, c->words.data(), c->N, c->S, c->maxL, (int)c->cfg.min_overlap, c->err);
+    int minL = c->N ? 0xFFFF : 0; for (uint64_t i = 1; i <= c->N; i++) minL = std::min<int>(minL, c->len[i]);
+    int rc = dev_upload_reads(c->dev, c->words.data(), c->N, c->S, minL, c->maxL, (int)c->cfg.min_overlap, c->err);
     if (rc) return rc;
     c->organized = true; c->indexBuilt = c->probed = c->reciprocalDone = c->reduced = c->converted = false;
     return SAGE2OV_OK;
@@ -331,7 +332,8 @@ int sage2ov_reads_organize(sage2ov_ctx* c) {                                    
     for (uint64_t i = 0; i < n; i++) if (c->poolLen[i] == 0xFFFF) return c->fail(SAGE2OV_ERR_LIMIT, "reads longer than 504 bases are not supported");
     if (c->dev && !getenv("SAGE2OV_HOST_ORGANIZE")) {                                 // step 1 on the device: canonical orientation, sort, unique, ids
         uint64_t N = 0;
-        int rc = dev_organize_reads(c->dev, c->pool.data(), c->pool.size(), c->poolOff.data(), c->poolLen.data(), n, c->S, c->maxL, (int)c->cfg.min_overlap,
+        int minL = n ? 0xFFFF : 0; for (uint64_t i = 0; i < n; i++) minL = std::min<int>(minL, c->poolLen[i]);
+        int rc = dev_organize_reads(c->dev, c->pool.data(), c->pool.size(), c->poolOff.data(), c->poolLen.data(), n, c->S, minL, c->maxL, (int)c->cfg.min_overlap,
                                     &N, c->words, c->freq, c->err);
         if (rc) return rc;
         c->N = N; c->len.assign(N + 1, 0);

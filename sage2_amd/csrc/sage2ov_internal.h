@@ -39,7 +39,7 @@ Device* dev_create(int device_ordinal, std::string& err);
 void dev_destroy(Device* d);
 void* dev_stream(Device* d);
 
-int dev_upload_reads(Device* d, const uint64_t* words, uint64_t N, int S, int maxL, int k, std::string& err);
+int dev_upload_reads(Device* d, const uint64_t* words, uint64_t N, int S, int minL, int maxL, int k, std::string& err);
 int dev_build_index(Device* d, uint64_t* slots, uint64_t* keys, uint64_t* csr, uint64_t* nlong, uint32_t* rebuilds, std::string& err);
 int dev_lookup(Device* d, uint64_t hi, uint64_t lo, uint64_t* entries, uint32_t cap, uint32_t* count, std::string& err);
 // probe+verify+extension kernel over ids [lo, hi)
@@ -61,7 +61,7 @@ int dev_unresolved_hits(Device* d, std::vector<Hit>& hits, uint64_t* n_unresolve
 int dev_download_status(Device* d, std::vector<uint8_t>& status, std::string& err);
 int dev_unresolved_ids(Device* d, std::vector<uint32_t>& ids, std::string& err);          // ascending
 int dev_collect_reduce_edges(Device* d, std::vector<EdgeCand>& out, std::string& err);
-int dev_organize_reads(Device* d, const uint64_t* pool, uint64_t pool_words, const uint64_t* off, const uint16_t* len, uint64_t n, int S, int maxL, int k,
+int dev_organize_reads(Device* d, const uint64_t* pool, uint64_t pool_words, const uint64_t* off, const uint16_t* len, uint64_t n, int S, int minL, int maxL, int k,
                        uint64_t* N_out, std::vector<uint64_t>& words_out, std::vector<uint16_t>& freq_out, std::string& err);
 int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved, uint64_t* n_hits, uint64_t* inserted, uint64_t* removed, int* done, std::string& err);
 // append host-computed edge candidates (from the reduce replay) to the device candidate list
