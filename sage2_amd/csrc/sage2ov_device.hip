@@ -1485,24 +1485,35 @@ __device__ __forceinline__ EdgeCand make_edge(const u64* reads, int S, int uniL,
     }
     return e;
 }
-__global__ void k_recip_emit(u64 N, const u64* __restrict__ reads, int S, int uniL, const u64* __restrict__ right, const u64* __restrict__ left,
+constexpr int EMIT_PER_THREAD = 16;               // reads per thread: a block of 256 threads reserves space for 4096 reads with ONE atomic
+__global__ __launch_bounds__(256) void k_recip_emit(u64 N, const u64* __restrict__ reads, int S, int uniL, const u64* __restrict__ right, const u64* __restrict__ left,
                              const uint8_t* __restrict__ status, EdgeCand* cand, u64 cap, u64* counters, u64 elo, u64 ehi) {
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x + elo;
-    const bool act = i < ehi && i <= N && status[i] == 4;
-    u64 l = 0, r = 0, lid = 0, rid = 0; bool eL = false, eR = false;
-    if (act) {
-        l = left[i]; r = right[i]; lid = l & ID_MASK; rid = r & ID_MASK;
-        eL = lid != i && !(lid < i && status[lid] == 4);                                    // :462-467 (and u != v, :815)
-        eR = rid != i && !(rid < i && status[rid] == 4);                                    // :468-473
+    __shared__ u32 sh[4]; __shared__ u64 shBase;
+    const u64 tile0 = (u64)blockIdx.x * (256 * EMIT_PER_THREAD) + elo;
+    u32 flags = 0, mine = 0;
+#pragma unroll
+    for (int it = 0; it < EMIT_PER_THREAD; it++) {
+        const u64 i = tile0 + (u64)it * 256 + threadIdx.x;
+        if (i < ehi && i <= N && status[i] == 4) {
+            const u64 l = left[i], r = right[i], lid = l & ID_MASK, rid = r & ID_MASK;
+            const bool eL = lid != i && !(lid < i && status[lid] == 4);                     // :462-467 (and u != v, :815)
+            const bool eR = rid != i && !(rid < i && status[rid] == 4);                     // :468-473
+            flags |= ((eL ? 1u : 0u) | (eR ? 2u : 0u)) << (2 * it); mine += (eL ? 1u : 0u) + (eR ? 1u : 0u);
+        }
     }
-    // one atomic per wave: positions by ballot prefix
-    const u64 bL = __ballot(eL), bR = __ballot(eR); const u32 nL = (u32)__popcll(bL), nR = (u32)__popcll(bR);
-    if (nL + nR == 0) return;
-    u64 base = 0; if (lane_id() == 0) base = atomicAdd(&counters[0], (u64)(nL + nR));
-    base = __shfl(base, 0);
-    const u64 lt = (1ull << lane_id()) - 1ull;
-    if (eL) { const u64 p = base + __popcll(bL & lt); if (p < cap) cand[p] = make_edge(reads, S, uniL, i, lid, (u32)(l >> 42), ((l >> 40) & 3) == 0 ? 0u : 1u); }
-    if (eR) { const u64 p = base + nL + __popcll(bR & lt); if (p < cap) cand[p] = make_edge(reads, S, uniL, i, rid, (u32)(r >> 42), ((r >> 40) & 3) == 0 ? 3u : 2u); }
+    u32 total; const u32 excl = block_excl_scan(mine, sh, total);
+    if (total == 0) return;
+    if (threadIdx.x == 0) shBase = atomicAdd(&counters[0], (u64)total);
+    __syncthreads();
+    u64 p = shBase + excl;
+#pragma unroll
+    for (int it = 0; it < EMIT_PER_THREAD; it++) {
+        const u32 f = (flags >> (2 * it)) & 3u; if (!f) continue;
+        const u64 i = tile0 + (u64)it * 256 + threadIdx.x;
+        const u64 l = left[i], r = right[i];
+        if (f & 1u) { if (p < cap) cand[p] = make_edge(reads, S, uniL, i, l & ID_MASK, (u32)(l >> 42), ((l >> 40) & 3) == 0 ? 0u : 1u); p++; }
+        if (f & 2u) { if (p < cap) cand[p] = make_edge(reads, S, uniL, i, r & ID_MASK, (u32)(r >> 42), ((r >> 40) & 3) == 0 ? 3u : 2u); p++; }
+    }
 }
 
 // reduce-phase support: the host replay needs the lists of unresolved reads and of their neighbours
@@ -2071,7 +2082,7 @@ int dev_reciprocal(Device* d, uint64_t emit_lo, uint64_t emit_hi, uint64_t* n_ov
     HIPCHK(hipMemsetAsync(d->status, 0, N + 1, d->stream));
     hipLaunchKernelGGL(k_recip_cond, dim3(grid_for(N, 256)), dim3(256), 0, d->stream, N, d->right, d->left, d->conn, d->cflag, d->status, d->d_counters);
     if (emit_hi > emit_lo)
-        hipLaunchKernelGGL(k_recip_emit, dim3(grid_for(emit_hi - emit_lo, 256)), dim3(256), 0, d->stream, N, d->reads, d->S, d->uniL, d->right, d->left, d->status, d->cand, d->cand_cap, d->d_counters, (u64)emit_lo, (u64)emit_hi);
+        hipLaunchKernelGGL(k_recip_emit, dim3(grid_for(emit_hi - emit_lo, 256 * EMIT_PER_THREAD)), dim3(256), 0, d->stream, N, d->reads, d->S, d->uniL, d->right, d->left, d->status, d->cand, d->cand_cap, d->d_counters, (u64)emit_lo, (u64)emit_hi);
     u64 c[8];
     HIPCHK(hipMemcpyAsync(c, d->d_counters, sizeof c, hipMemcpyDeviceToHost, d->stream));
     HIPCHK(hipEventRecord(d->ev[1], d->stream));
