@@ -393,7 +393,7 @@ __device__ __forceinline__ u32 block_excl_scan(u32 v, u32* sh, u32& total);
 // counters: [0] csr total, [1] occupied slots, [2] number of big buckets, [3] impurity flag, [4] pure long buckets
 // One block owns ALLOC_ITEMS consecutive slots and draws its CSR space with ONE atomic (a per-wave atomic on
 // the same word serialises: 25 ms for 68 M slots; this form streams at HBM speed).
-constexpr int ALLOC_PER_THREAD = 16, ALLOC_ITEMS = 256 * ALLOC_PER_THREAD;
+constexpr int ALLOC_PER_THREAD = 64, ALLOC_ITEMS = 256 * ALLOC_PER_THREAD;   // 16384 slots per block: its two atomics stay off the critical path
 __global__ __launch_bounds__(256) void k_index_alloc(u64* slots, u64 T, u64* counters, u64* big, u32 big_cap) {
     __shared__ u32 sh[4]; __shared__ u64 shBase;
     const u64 base0 = (u64)blockIdx.x * ALLOC_ITEMS;
@@ -1446,30 +1446,36 @@ __global__ __launch_bounds__(64 * WPB, SAGE2OV_FAST_WAVES) void k_probe_fast(Pro
 //   is visited is true iff NOT (x < i and cond(x)).
 // =============================================================================================
 constexpr u64 ID_MASK = (1ull << 40) - 1;
-__global__ void k_recip_cond(u64 N, const u64* __restrict__ right, const u64* __restrict__ left, const u32* __restrict__ conn,
+constexpr int COND_PER_THREAD = 8;                // reads per thread: the three log counters cost three atomics per 2048 reads
+__global__ __launch_bounds__(256) void k_recip_cond(u64 N, const u64* __restrict__ right, const u64* __restrict__ left, const u32* __restrict__ conn,
                              const u32* __restrict__ cflag, uint8_t* status, u64* counters) {
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x + 1;
-    u32 c = 0; bool cond = false, is6 = false;
-    if (i <= N) {
-        c = conn[i]; u32 cf = cflag[i]; bool over = c > CONN_LIMIT;
-        is6 = (cf & 1u) || ((cf & 2u) && !over);        // single-thread outcome of the :444 / :735 writes
-        u64 l = left[i], r = right[i]; u64 lid = l & ID_MASK, rid = r & ID_MASK;
-        if (!is6 && (l >> 42) != 0 && (r >> 42) != 0) {
-            bool lrec = ((right[lid] & ID_MASK) == i) || ((left[lid] & ID_MASK) == i);
-            bool rrec = ((right[rid] & ID_MASK) == i) || ((left[rid] & ID_MASK) == i);
-            cond = lrec && rrec;
+    u64 ovs = 0; u32 ncond = 0, n6 = 0;
+#pragma unroll
+    for (int it = 0; it < COND_PER_THREAD; it++) {
+        const u64 i = (u64)blockIdx.x * (256 * COND_PER_THREAD) + (u64)it * 256 + threadIdx.x + 1;
+        if (i <= N) {
+            const u32 c = conn[i], cf = cflag[i]; const bool over = c > CONN_LIMIT;
+            const bool is6 = (cf & 1u) || ((cf & 2u) && !over);        // single-thread outcome of the :444 / :735 writes
+            const u64 l = left[i], r = right[i]; const u64 lid = l & ID_MASK, rid = r & ID_MASK;
+            bool cond = false;
+            if (!is6 && (l >> 42) != 0 && (r >> 42) != 0) {
+                const bool lrec = ((right[lid] & ID_MASK) == i) || ((left[lid] & ID_MASK) == i);
+                const bool rrec = ((right[rid] & ID_MASK) == i) || ((left[rid] & ID_MASK) == i);
+                cond = lrec && rrec;
+            }
+            status[i] = cond ? 4 : (is6 ? 6 : (over ? 5 : 0));
+            ovs += c; ncond += cond; n6 += is6;
         }
-        status[i] = cond ? 4 : (is6 ? 6 : (over ? 5 : 0));
     }
     // block reductions of the log counters: one atomic per counter per block
     __shared__ u64 red[3][4];
-    u64 ov = c; for (int d = 32; d; d >>= 1) ov += __shfl_xor(ov, d);
-    const u64 bc = __ballot(cond), b6 = __ballot(is6);
+    u64 v0 = ovs, v1 = ncond, v2 = n6;
+    for (int d = 32; d; d >>= 1) { v0 += __shfl_xor(v0, d); v1 += __shfl_xor(v1, d); v2 += __shfl_xor(v2, d); }
     const u32 w = threadIdx.x >> 6;
-    if (lane_id() == 0) { red[0][w] = ov; red[1][w] = (u64)__popcll(bc); red[2][w] = (u64)__popcll(b6); }
+    if (lane_id() == 0) { red[0][w] = v0; red[1][w] = v1; red[2][w] = v2; }
     __syncthreads();
     if (threadIdx.x < 3) {
-        u64 t = 0; for (u32 x = 0; x < blockDim.x / 64; x++) t += red[threadIdx.x][x];
+        u64 t = 0; for (u32 x = 0; x < 4; x++) t += red[threadIdx.x][x];
         if (t) atomicAdd(&counters[1 + threadIdx.x], t);
     }
 }
@@ -1528,15 +1534,20 @@ __global__ void k_red_collect(EdgeCand* cand, u64 n, const uint8_t* __restrict__
     if (need[e.from] || need[e.to]) { u64 p = atomicAdd(counter, 1ull); if (p < cap) out[p] = e; }
     if (status[e.from] == 0) cand[x].type = e.type | 0x80u;    // list of an unresolved read: rewritten by the replay
 }
-__global__ void k_red_unresolved(u64 N, const uint8_t* __restrict__ status, u32* out, u64 cap, u64* counter) {
-    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x + 1;
-    const bool un = i <= N && status[i] == 0;
-    const u64 bal = __ballot(un);                                       // one atomic per wave (most reads are unresolved on noisy data)
-    if (bal == 0) return;
-    u64 base = 0; if (lane_id() == (u32)__builtin_ctzll(bal)) base = atomicAdd(counter, (u64)__popcll(bal));
-    base = __shfl(base, __builtin_ctzll(bal));
-    const u64 p = base + (u64)__popcll(bal & ((1ull << lane_id()) - 1ull));
-    if (un && p < cap) out[p] = (u32)i;
+constexpr int UNRES_PER_THREAD = 16;
+__global__ __launch_bounds__(256) void k_red_unresolved(u64 N, const uint8_t* __restrict__ status, u32* out, u64 cap, u64* counter) {
+    __shared__ u32 sh[4]; __shared__ u64 shBase;
+    const u64 tile0 = (u64)blockIdx.x * (256 * UNRES_PER_THREAD) + 1;
+    u32 flags = 0, mine = 0;
+#pragma unroll
+    for (int it = 0; it < UNRES_PER_THREAD; it++) { const u64 i = tile0 + (u64)it * 256 + threadIdx.x; if (i <= N && status[i] == 0) { flags |= 1u << it; mine++; } }
+    u32 total; const u32 excl = block_excl_scan(mine, sh, total);
+    if (total == 0) return;
+    if (threadIdx.x == 0) shBase = atomicAdd(counter, (u64)total);                 // one atomic per 4096 reads (most reads are unresolved on noisy data)
+    __syncthreads();
+    u64 p = shBase + excl;
+#pragma unroll
+    for (int it = 0; it < UNRES_PER_THREAD; it++) if (flags & (1u << it)) { if (p < cap) out[p] = (u32)(tile0 + (u64)it * 256 + threadIdx.x); p++; }
 }
 
 // =============================================================================================
@@ -1599,6 +1610,7 @@ __global__ __launch_bounds__(256) void k_ra_mark(const u32* __restrict__ ids, u6
     __shared__ RaLds lds[4];
     RaLds& L = lds[threadIdx.x >> 6];
     const u32 lane = lane_id();
+    u64 removedTotal = 0;
     for (u64 w = (u64)blockIdx.x * 4 + (threadIdx.x >> 6); w < nids; w += (u64)gridDim.x * 4) {
         const u32 r = ids[w]; const u32 n = deg[r]; const u32 o = offs[r];
         if (n == 0) { if (lane == 0) svn[w] = 0; continue; }
@@ -1657,8 +1669,10 @@ __global__ __launch_bounds__(256) void k_ra_mark(const u32* __restrict__ ids, u6
             nrm += gone; nsv += (!gone && ra_to(kx) > r);
         }
         for (int dlt = 32; dlt; dlt >>= 1) { nrm += __shfl_xor(nrm, dlt); nsv += __shfl_xor(nsv, dlt); }
-        if (lane == 0) { svn[w] = nsv; if (nrm) atomicAdd(&counters[1], (u64)nrm); }
+        if (lane == 0) svn[w] = nsv;
+        removedTotal += nrm;
     }
+    if (lane == 0 && removedTotal) atomicAdd(&counters[1], removedTotal);       // one atomic per wave, not per read
 }
 __global__ void k_ra_emit(const u32* __restrict__ ids, u64 nids, const u32* __restrict__ offs, const u32* __restrict__ deg, const u64* __restrict__ ent,
                           const uint8_t* __restrict__ rm, const u32* __restrict__ svoff, EdgeCand* cand, u64 base, u64 cap) {
@@ -2080,7 +2094,7 @@ int dev_reciprocal(Device* d, uint64_t emit_lo, uint64_t emit_hi, uint64_t* n_ov
     HIPCHK(hipEventRecord(d->ev[0], d->stream));
     HIPCHK(hipMemsetAsync(d->d_counters, 0, 8 * sizeof(u64), d->stream));
     HIPCHK(hipMemsetAsync(d->status, 0, N + 1, d->stream));
-    hipLaunchKernelGGL(k_recip_cond, dim3(grid_for(N, 256)), dim3(256), 0, d->stream, N, d->right, d->left, d->conn, d->cflag, d->status, d->d_counters);
+    hipLaunchKernelGGL(k_recip_cond, dim3(grid_for(N, 256 * COND_PER_THREAD)), dim3(256), 0, d->stream, N, d->right, d->left, d->conn, d->cflag, d->status, d->d_counters);
     if (emit_hi > emit_lo)
         hipLaunchKernelGGL(k_recip_emit, dim3(grid_for(emit_hi - emit_lo, 256 * EMIT_PER_THREAD)), dim3(256), 0, d->stream, N, d->reads, d->S, d->uniL, d->right, d->left, d->status, d->cand, d->cand_cap, d->d_counters, (u64)emit_lo, (u64)emit_hi);
     u64 c[8];
@@ -2155,7 +2169,7 @@ int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved
         for (int attempt = 0; attempt < 2; attempt++) {
             WS(buf, u32, WS_IDS, cap); ids = buf;
             HIPCHK(hipMemsetAsync(d->d_counters + 5, 0, sizeof(u64), d->stream));
-            hipLaunchKernelGGL(k_red_unresolved, dim3(grid_for(N, 256)), dim3(256), 0, d->stream, (u64)N, d->status, buf, cap, d->d_counters + 5);
+            hipLaunchKernelGGL(k_red_unresolved, dim3(grid_for(N, 256 * UNRES_PER_THREAD)), dim3(256), 0, d->stream, (u64)N, d->status, buf, cap, d->d_counters + 5);
             HIPCHK(hipMemcpyAsync(&nun, d->d_counters + 5, sizeof nun, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
             if (nun <= cap) break;
             cap = nun;
@@ -2263,7 +2277,7 @@ int dev_unresolved_ids(Device* d, std::vector<uint32_t>& ids, std::string& err) 
     for (int attempt = 0; attempt < 2; attempt++) {
         WS(buf, u32, WS_IDS, cap);
         HIPCHK(hipMemsetAsync(d->d_counters + 5, 0, sizeof(u64), d->stream));
-        hipLaunchKernelGGL(k_red_unresolved, dim3(grid_for(d->N, 256)), dim3(256), 0, d->stream, (u64)d->N, d->status, buf, cap, d->d_counters + 5);
+        hipLaunchKernelGGL(k_red_unresolved, dim3(grid_for(d->N, 256 * UNRES_PER_THREAD)), dim3(256), 0, d->stream, (u64)d->N, d->status, buf, cap, d->d_counters + 5);
         u64 cnt = 0; HIPCHK(hipMemcpyAsync(&cnt, d->d_counters + 5, sizeof cnt, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
         if (cnt <= cap) { ids.resize(cnt); if (cnt) HIPCHK(hipMemcpy(ids.data(), buf, cnt * sizeof(u32), hipMemcpyDeviceToHost)); std::sort(ids.begin(), ids.end()); return 0; }
         cap = cnt;
