@@ -388,3 +388,21 @@ def test_full_size_properties_c2():
     ctx.run_steps23()
     assert zlib.crc32(ctx.edges().tobytes()) == crc
     ctx.close()
+
+
+def test_high_coverage_many_candidates_match_oracle(reduce_path):
+    """150x coverage: most reads have more than 128 candidates, so the fast kernel (extension records and hit lists alike) hands
+    them to the sequential kernel, connection counts pass the 300 limit (status 5), and the reduce phase sees long lists."""
+    pd = dict(seed=31, genome_len=20000, n_reads=30000, read_len=100, err_ppm=1000)
+    bases, off = fx.make_reads(pd)
+    m = dict(k=21)
+    g, o = run_gpu(m, bases, off), run_oracle(m, bases, off)
+    gr, gl, gs, gc = g.overlap_export_initial(); orr, orl, ors, orc = o.export_initial()
+    assert np.array_equal(gc, orc) and np.array_equal(gr[1:], orr[1:]) and np.array_equal(gl[1:], orl[1:])
+    assert int((gc > 128).sum()) > 1000, "the data set is meant to overflow the 128-candidate batches"
+    e, oe = g.edges(), o.export_edges()
+    assert len(e) == len(oe) and np.array_equal(e["from"], oe[:, 0]) and np.array_equal(e["to"], oe[:, 1])
+    assert np.array_equal(e["type"], oe[:, 2]) and np.array_equal(e["length"], oe[:, 3]) and np.array_equal(e["length_twin"], oe[:, 4])
+    st = g.overlap_stats()
+    assert (st.edges_inserted, st.transitive_removed) == (o.counter("edges_inserted"), o.counter("transitive_removed"))
+    g.close(); o.close()
