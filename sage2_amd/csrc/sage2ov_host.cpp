@@ -141,83 +141,102 @@ std::string trim(const std::string& s) { size_t a = s.find_first_not_of(" \t\r\n
 
 // ------------------------------------------------------------------------------------------ reduce replay
 // exact restatement of economyGraph.cpp:495-574 over device-computed hit lists
+// Serial replay of the reduce phase (economyGraph.cpp:513-707).  All state is in flat arrays over a dense numbering of the reads
+// it can touch (unresolved reads and the ends of the candidates near them): no hashing on the hot path.
 struct Replay {
     sage2ov_ctx* c;
-    std::unordered_map<uint32_t, std::vector<AdjEdge>> adj;
-    std::unordered_map<uint32_t, uint8_t> st;        // unresolved reads only: 0 unexplored, 1 explored, 2 marked
-    std::unordered_map<uint32_t, std::pair<uint64_t, uint64_t>> hitRange;
-    std::unordered_map<uint32_t, uint8_t> mk;
+    std::vector<uint32_t> dense;                       // read id -> dense index + 1 (0: not part of the replay)
+    std::vector<uint32_t> idOf;                        // dense index -> read id
+    std::vector<std::vector<AdjEdge>> adj;             // per dense index
+    std::vector<uint8_t> st;                           // per dense index: 0 unexplored, 1 explored, 2 marked, 4 not an unresolved read
+    std::vector<std::pair<uint64_t, uint64_t>> hitRange;
     const std::vector<Hit>* hits = nullptr;
     uint64_t inserted = 0, removed = 0;
-    uint8_t status(uint32_t r) const { auto it = st.find(r); return it == st.end() ? 4 : it->second; }
-    int insert_edge(uint32_t u, uint32_t v, uint32_t delta, int type) {              // economyGraph.cpp:813-849
+    uint32_t add(uint32_t id) { uint32_t& d = dense[id]; if (!d) { idOf.push_back(id); d = (uint32_t)idOf.size(); } return d - 1; }
+    void finish_setup() { adj.resize(idOf.size()); st.assign(idOf.size(), 4); hitRange.assign(idOf.size(), {0, 0}); }
+    uint8_t status_id(uint32_t id) const { const uint32_t d = dense[id]; return d ? st[d - 1] : 4; }
+    int insert_edge(uint32_t u, uint32_t v, uint32_t delta, int type) {              // economyGraph.cpp:813-849 (u, v: read ids)
         if (u == v) return 0;
         int d2 = (int)c->len[u] - ((int)c->len[v] - (int)delta);
-        adj[u].push_back(AdjEdge{v, (uint8_t)type, 0, delta & 0xFFFFFu});
-        adj[v].push_back(AdjEdge{u, (uint8_t)flip_type_host(type), 0, (uint32_t)d2 & 0xFFFFFu});
+        adj[dense[u] - 1].push_back(AdjEdge{v, (uint8_t)type, 0, delta & 0xFFFFFu});
+        adj[dense[v] - 1].push_back(AdjEdge{u, (uint8_t)flip_type_host(type), 0, (uint32_t)d2 & 0xFFFFFu});
         return 1;
     }
     uint64_t explore(uint32_t r1) {                                                  // economyGraph.cpp:580-638
-        auto it = st.find(r1); if (it == st.end() || it->second != 0) return 0;
-        it->second = 1; uint64_t ins = 0;
-        auto hr = hitRange.find(r1);
-        if (hr != hitRange.end())
-            for (uint64_t x = hr->second.first; x < hr->second.second; x++) {
-                const Hit& h = (*hits)[x];
-                if (status(h.to) != 0) continue;                                     // :605 current status
-                if (h.len == -1) continue;                                           // :627 sentinel quirk
-                ins += insert_edge(r1, h.to, (uint32_t)h.len, h.type);
-            }
-        auto& a = adj[r1];
+        const uint32_t d1 = dense[r1]; if (!d1 || st[d1 - 1] != 0) return 0;
+        st[d1 - 1] = 1; uint64_t ins = 0;
+        for (uint64_t x = hitRange[d1 - 1].first; x < hitRange[d1 - 1].second; x++) {
+            const Hit& h = (*hits)[x];
+            if (status_id(h.to) != 0) continue;                                      // :605 current status
+            if (h.len == -1) continue;                                               // :627 sentinel quirk
+            ins += insert_edge(r1, h.to, (uint32_t)h.len, h.type);
+        }
+        auto& a = adj[d1 - 1];
         if (a.size() > 1) std::sort(a.begin(), a.end(), [](const AdjEdge& x, const AdjEdge& y) {   // :853-871
             if (x.len != y.len) return x.len > y.len; if (x.to != y.to) return x.to > y.to; return x.type > y.type; });
         return ins * 2;
     }
-    void mark(uint32_t from) {                                                       // economyGraph.cpp:643-679
-        auto& a = adj[from];
-        for (auto& e : a) mk[e.to] = 1;
+    // markTransitiveEdge (economyGraph.cpp:643-679).  When it runs in the serial BFS the lists of `from` and of all its neighbours are
+    // complete and nothing has been removed from them yet (every neighbour is explored by then, nobody appends to the list of an
+    // explored read, and a read's removal waits until all its neighbours are marked): the marks are a function of the final lists, so
+    // the BFS below only keeps the statuses that steer the traversal and the marks are computed afterwards, reads in parallel.
+    void mark_edges(uint32_t from, std::vector<uint8_t>& mkb) {
+        auto& a = adj[dense[from] - 1];
+        for (auto& e : a) mkb[dense[e.to] - 1] = 1;
         for (auto& e : a) {
-            if (mk[e.to] != 1) continue;
-            auto it = adj.find(e.to); if (it == adj.end()) continue;
-            for (auto& f : it->second) {
-                auto m = mk.find(f.to); if (m == mk.end() || m->second != 1) continue;
+            if (mkb[dense[e.to] - 1] != 1) continue;
+            for (auto& f : adj[dense[e.to] - 1]) {
+                const uint32_t df = dense[f.to]; if (!df || mkb[df - 1] != 1) continue;
                 int t1 = e.type, t2 = f.type;
-                if ((t1 == 0 || t1 == 2) && (t2 == 0 || t2 == 1)) m->second = 2;
-                else if ((t1 == 1 || t1 == 3) && (t2 == 2 || t2 == 3)) m->second = 2;
+                if ((t1 == 0 || t1 == 2) && (t2 == 0 || t2 == 1)) mkb[df - 1] = 2;
+                else if ((t1 == 1 || t1 == 3) && (t2 == 2 || t2 == 3)) mkb[df - 1] = 2;
             }
         }
-        for (auto& e : a) if (mk[e.to] == 2) e.mark = 1;
-        mk.clear();
-        st[from] = 2;
+        for (auto& e : a) if (mkb[dense[e.to] - 1] == 2) e.mark = 1;
+        for (auto& e : a) mkb[dense[e.to] - 1] = 0;
     }
+    void mark(uint32_t from) { st[dense[from] - 1] = 2; }                            // traversal only: status 1 -> 2 (:679)
     uint64_t remove_marked(uint32_t r) {                                             // economyGraph.cpp:681-707
-        auto& a = adj[r]; size_t before = a.size();
+        auto& a = adj[dense[r] - 1]; size_t before = a.size();
         a.erase(std::remove_if(a.begin(), a.end(), [](const AdjEdge& e) { return e.mark != 0; }), a.end());
         return before - a.size();
     }
     void run(const std::vector<uint32_t>& ids) {
         std::vector<uint32_t> queue;
-        for (uint32_t i : ids) {
-            if (status(i) != 0) continue;
+        for (uint32_t i : ids) {                                                     // the serial part: exploration order (:513-564)
+            if (status_id(i) != 0) continue;
             queue.clear(); size_t start = 0; queue.push_back(i);
             while (start < queue.size()) {
                 uint32_t r1 = queue[start++];
-                if (status(r1) == 0) inserted += explore(r1);
-                auto it = adj.find(r1); if (it == adj.end() || it->second.empty()) continue;
-                if (status(r1) == 1) {
-                    for (size_t x = 0; x < adj[r1].size(); x++) { uint32_t r2 = adj[r1][x].to; if (status(r2) == 0) { queue.push_back(r2); inserted += explore(r2); } }
+                if (status_id(r1) == 0) inserted += explore(r1);
+                const uint32_t d1 = dense[r1] - 1;
+                if (adj[d1].empty()) continue;
+                if (st[d1] == 1) {
+                    for (size_t x = 0; x < adj[d1].size(); x++) { uint32_t r2 = adj[d1][x].to; if (status_id(r2) == 0) { queue.push_back(r2); inserted += explore(r2); } }
                     mark(r1);
                 }
-                if (status(r1) == 2) {
-                    for (size_t x = 0; x < adj[r1].size(); x++) {
-                        uint32_t r2 = adj[r1][x].to; if (status(r2) != 1) continue;
-                        for (size_t y = 0; y < adj[r2].size(); y++) { uint32_t r3 = adj[r2][y].to; if (status(r3) == 0) { queue.push_back(r3); inserted += explore(r3); } }
+                if (st[d1] == 2) {
+                    for (size_t x = 0; x < adj[d1].size(); x++) {
+                        uint32_t r2 = adj[d1][x].to; if (status_id(r2) != 1) continue;
+                        const uint32_t d2 = dense[r2] - 1;
+                        for (size_t y = 0; y < adj[d2].size(); y++) { uint32_t r3 = adj[d2][y].to; if (status_id(r3) == 0) { queue.push_back(r3); inserted += explore(r3); } }
                         mark(r2);
                     }
-                    removed += remove_marked(r1);
                 }
             }
         }
+        // marks on the final lists (all reads first: they read their neighbours' unreduced lists), then the removals (:681-707)
+        const int64_t n = (int64_t)ids.size();
+        #pragma omp parallel
+        {
+            std::vector<uint8_t> mkb(idOf.size(), 0);
+            #pragma omp for schedule(dynamic, 1024)
+            for (int64_t x = 0; x < n; x++) { const uint32_t d = dense[ids[x]] - 1; if (st[d] == 2 && !adj[d].empty()) mark_edges(ids[x], mkb); }
+        }
+        uint64_t rem = 0;
+        #pragma omp parallel for schedule(dynamic, 1024) reduction(+ : rem)
+        for (int64_t x = 0; x < n; x++) { const uint32_t d = dense[ids[x]] - 1; if (st[d] == 2) rem += remove_marked(ids[x]); }
+        removed += rem;
     }
 };
 
@@ -549,20 +568,25 @@ int sage2ov_overlap_reduce(sage2ov_ctx* c) {
         std::vector<EdgeCand> near; rc = dev_collect_reduce_edges(c->dev, near, c->err); if (rc) return rc;
         __gnu_parallel::sort(hits.begin(), hits.end(), [](const Hit& a, const Hit& b) { return a.from != b.from ? a.from < b.from : a.seq < b.seq; });
         Replay R; R.c = c; R.hits = &hits;
-        R.st.reserve(ids.size() * 2); for (uint32_t i : ids) R.st[i] = 0;
-        for (uint64_t x = 0; x < hits.size();) { uint64_t y = x; while (y < hits.size() && hits[y].from == hits[x].from) y++; R.hitRange[hits[x].from] = {x, y}; x = y; }
+        R.dense.assign(c->N + 2, 0);
+        for (uint32_t i : ids) R.add(i);
+        for (auto& e : near) { R.add(e.from); R.add(e.to); }
+        for (auto& h : hits) R.add(h.to);                                              // (status-0 reads: already in, kept for safety)
+        R.finish_setup();
+        for (uint32_t i : ids) R.st[R.dense[i] - 1] = 0;
+        for (uint64_t x = 0; x < hits.size();) { uint64_t y = x; while (y < hits.size() && hits[y].from == hits[x].from) y++; R.hitRange[R.dense[hits[x].from] - 1] = {x, y}; x = y; }
         for (auto& e : near) {                                                        // both directed entries of every stored edge
-            R.adj[e.from].push_back(AdjEdge{e.to, (uint8_t)e.type, 0, e.len});
+            R.adj[R.dense[e.from] - 1].push_back(AdjEdge{e.to, (uint8_t)e.type, 0, e.len});
             // e is the entry of list[from]; it was created either directly (u=from) or as the twin of (u=to): either way
             // list[to] holds the involutive twin, length L_from - (L_to - len)  (economyGraph.cpp:821)
             const int d2 = (int)c->len[e.from] - ((int)c->len[e.to] - (int)e.len);
-            R.adj[e.to].push_back(AdjEdge{e.from, (uint8_t)flip_type_host(e.type), 0, (uint32_t)d2 & 0xFFFFFu});
+            R.adj[R.dense[e.to] - 1].push_back(AdjEdge{e.from, (uint8_t)flip_type_host(e.type), 0, (uint32_t)d2 & 0xFFFFFu});
         }
         R.run(ids);
         c->ostats.edges_inserted = R.inserted; c->ostats.transitive_removed = R.removed;
         // surviving list entries of unresolved reads with to > from replace what the device dropped
         std::vector<EdgeCand> survivors;
-        for (uint32_t i : ids) { auto it = R.adj.find(i); if (it == R.adj.end()) continue; for (auto& e : it->second) if (e.to > i) survivors.push_back(EdgeCand{i, e.to, e.len, e.type}); }
+        for (uint32_t i : ids) for (auto& e : R.adj[R.dense[i] - 1]) if (e.to > i) survivors.push_back(EdgeCand{i, e.to, e.len, e.type});
         rc = dev_append_edges(c->dev, survivors.data(), survivors.size(), c->err); if (rc) return rc;
     }
     c->reduce_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
