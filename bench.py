@@ -140,6 +140,7 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--cpu-port", action="store_true", help="time the CPU restatement instead of oracle/_ref")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-noisy-variant", action="store_true", help="skip the secondary line: the same workload with 0.1 %% substitution errors (SURVEY 8d)")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -277,6 +278,25 @@ def main():
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": a_probe * share,
                          "whole_path_achieved": a_total / (elapsed / args.steps) / 1e9, "whole_path_frac": a_total / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
         }
+        if world == 1 and not args.no_noisy_variant and args.err_ppm == 0:
+            # secondary workload of SURVEY 8(d): the same reads with 0.1 % substitution errors (98 % of the reads then go through the
+            # reduce phase); same timed region, two steps
+            ctx.close()
+            pn = fx.synth_params(dict(pd, err_ppm=1000))
+            cn = s2.Context(args.k, device=local)
+            cn.reads_add_synth(pn, g); cn.reads_organize()
+            cn.run_steps23(); torch.cuda.synchronize()
+            tn = time.perf_counter(); nsteps = 2; phn = dict(index_ms=0.0, probe_ms=0.0, reciprocal_ms=0.0, reduce_ms=0.0, convert_ms=0.0)
+            for _ in range(nsteps):
+                cn.run_steps23(); tmn = cn.timings()
+                for kph in phn:
+                    phn[kph] += getattr(tmn, kph)
+            torch.cuda.synchronize(); en = (time.perf_counter() - tn) / nsteps
+            on = cn.overlap_stats()
+            res["noisy_variant"] = {"err_ppm": 1000, "ms_per_step": 1e3 * en, "value": on.verified_overlaps / en, "unit": "overlaps/s", "steps": nsteps,
+                                    "unique_reads": cn.reads_stats().unique_reads, "verified_overlaps": on.verified_overlaps, "edges": on.edges,
+                                    "unresolved_reads": on.left_to_explore, "phases_ms": {kph: v / nsteps for kph, v in phn.items()}}
+            cn.close()
         if world == 1 and not args.no_cpu_baseline:
             ctx.close()
             res["cpu_baseline"] = cpu_baseline_subprocess(args)

@@ -59,6 +59,7 @@ struct sage2ov_ctx {
     // ---- step 1 staging: variable-length word-packed canonical reads
     std::vector<uint64_t> pool; std::vector<uint64_t> poolOff; std::vector<uint16_t> poolLen;
     uint64_t totalReads = 0, goodReads = 0, totalBP = 0, smallReads = 0;
+    std::vector<uint32_t> replayDense;                 // scratch of the host replay (read id -> dense index), all zero between calls
     // ---- organised reads (host copy, ids 1..N)
     uint64_t N = 0; int S = 0, maxL = 0; bool organized = false;
     std::vector<uint64_t> words; std::vector<uint16_t> len, freq;
@@ -145,7 +146,9 @@ std::string trim(const std::string& s) { size_t a = s.find_first_not_of(" \t\r\n
 // it can touch (unresolved reads and the ends of the candidates near them): no hashing on the hot path.
 struct Replay {
     sage2ov_ctx* c;
-    std::vector<uint32_t> dense;                       // read id -> dense index + 1 (0: not part of the replay)
+    std::vector<uint32_t>& dense;                      // read id -> dense index + 1 (0: not part of the replay); lives in the context, all zero between replays
+    explicit Replay(std::vector<uint32_t>& d) : dense(d) {}
+    ~Replay() { for (uint32_t id : idOf) dense[id] = 0; }
     std::vector<uint32_t> idOf;                        // dense index -> read id
     std::vector<std::vector<AdjEdge>> adj;             // per dense index
     std::vector<uint8_t> st;                           // per dense index: 0 unexplored, 1 explored, 2 marked, 4 not an unresolved read
@@ -227,14 +230,14 @@ struct Replay {
         }
         // marks on the final lists (all reads first: they read their neighbours' unreduced lists), then the removals (:681-707)
         const int64_t n = (int64_t)ids.size();
-        #pragma omp parallel
+        #pragma omp parallel if (n > 4096)
         {
             std::vector<uint8_t> mkb(idOf.size(), 0);
             #pragma omp for schedule(dynamic, 1024)
             for (int64_t x = 0; x < n; x++) { const uint32_t d = dense[ids[x]] - 1; if (st[d] == 2 && !adj[d].empty()) mark_edges(ids[x], mkb); }
         }
         uint64_t rem = 0;
-        #pragma omp parallel for schedule(dynamic, 1024) reduction(+ : rem)
+        #pragma omp parallel for schedule(dynamic, 1024) reduction(+ : rem) if (n > 4096)
         for (int64_t x = 0; x < n; x++) { const uint32_t d = dense[ids[x]] - 1; if (st[d] == 2) rem += remove_marked(ids[x]); }
         removed += rem;
     }
@@ -567,8 +570,8 @@ int sage2ov_overlap_reduce(sage2ov_ctx* c) {
         std::vector<uint32_t> ids; rc = dev_unresolved_ids(c->dev, ids, c->err); if (rc) return rc;
         std::vector<EdgeCand> near; rc = dev_collect_reduce_edges(c->dev, near, c->err); if (rc) return rc;
         __gnu_parallel::sort(hits.begin(), hits.end(), [](const Hit& a, const Hit& b) { return a.from != b.from ? a.from < b.from : a.seq < b.seq; });
-        Replay R; R.c = c; R.hits = &hits;
-        R.dense.assign(c->N + 2, 0);
+        if (c->replayDense.size() != c->N + 2) c->replayDense.assign(c->N + 2, 0);
+        Replay R(c->replayDense); R.c = c; R.hits = &hits;
         for (uint32_t i : ids) R.add(i);
         for (auto& e : near) { R.add(e.from); R.add(e.to); }
         for (auto& h : hits) R.add(h.to);                                              // (status-0 reads: already in, kept for safety)

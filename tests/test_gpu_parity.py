@@ -319,7 +319,7 @@ def test_bench_two_ranks_sharing_the_gpu_agree_with_one_rank():
     (crc32 in the JSON line, asserted equal across ranks inside bench.py) must equal the single-rank one."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    common = ["--reads", "200000", "--genome", "600000", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"]
+    common = ["--reads", "200000", "--genome", "600000", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-noisy-variant"]
     env = dict(os.environ, SAGE2OV_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + common, check=True, capture_output=True, text=True, timeout=240)
     r1 = json.loads(one.stdout.strip().splitlines()[-1])

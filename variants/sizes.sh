@@ -2,7 +2,7 @@
 # kernel time per read at different dataset sizes (same coverage)
 for n in 500000 1000000 2000000 5000000 10000000; do
   g=$((n*3))
-  timeout -k 10 200 python3 bench.py --reads $n --genome $g --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | python3 -c "
+  timeout -k 10 200 python3 bench.py --reads $n --genome $g --steps 3 --warmup 1 --no-cpu-baseline --no-noisy-variant 2>/dev/null | python3 -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
