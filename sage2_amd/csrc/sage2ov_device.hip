@@ -819,6 +819,7 @@ struct FastLds {                   // every string has one zero dword in front (
     u32 candJ[FAST_CAP], candSrc[FAST_CAP];   // (after the entries are resolved the two arrays hold the packed geometry / read id of the verified hits)
     // inconsistent reads only (the in-kernel state machine): one padded row per lane to cut overhangs out of a candidate, and the
     // overhang of every verified hit (<= 128 bases) in this read's orientation
+    uint8_t tslotIdx[TAILED ? FAST_CAP : 4];          // slot number of the x-th verified hit (visiting order)
     u32 tslot[TAILED ? FAST_CAP : 1][TAILED ? NW + 3 : 1];   // per candidate slot: the candidate's dwords (zero dword in front, two behind), then its overhang in place
 };
 __device__ __forceinline__ u32 rev2_32(u32 x) { x = __brev(x); return ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1); }
@@ -829,6 +830,9 @@ __device__ __forceinline__ u32 funnel32(u32 a, u32 b, int r) { return (u32)(((((
 // One v_alignbit_b32 ({hi,lo} >> s, s in [0,31]): with q = (p-1)>>5 and s = (-p)&31 the aligned case (p%32 == 0) reads
 // the wanted dword as `lo` with s = 0, every other case is the usual funnel.  (D[q] is touched but unused when aligned.)
 __device__ __forceinline__ u32 get32(const u32* D, int p) { const int q = (p - 1) >> 5; return __builtin_amdgcn_alignbit(D[q], D[q + 1], (u32)(-p) & 31u); }
+// The masked overlap compares use get32(X, max(p, -32)): wherever the mask of a dword is non-zero its window starts at p >= -32 (the
+// overlap region maps to non-negative positions of this read and a dword reaches at most 16 bases in front of it), and it ends
+// inside the padded string (2*(16*9 + L1 - h) + 32 <= 32*(D+2)); fully masked dwords may read anything.
 // same with bounds: anything outside [0, 32*n) reads as zero, p may be any negative number (slow, rare paths only)
 __device__ __forceinline__ u32 get32z(const u32* D, int n, int p) {
     const int pp = p < 0 ? 0 : p, sh = pp - p, q = pp >> 5;
@@ -1155,7 +1159,7 @@ __global__ __launch_bounds__(64 * WPB, SAGE2OV_FAST_WAVES) void k_probe_fast(Pro
                         else if (t == 2) { dd = L1 - j - L2; lo = L2 - n; hi = L2; } else { dd = j + h - L2; lo = L2 - n; hi = L2; }
                         u32 diff = 0;
 #pragma unroll
-                        for (int c = 0; c < NW; c++) diff |= (Y[q][c] ^ get32z(X, D + 2, 2 * (16 * c + dd))) & range_mask32(lo - 16 * c, hi - 16 * c);
+                        for (int c = 0; c < NW; c++) diff |= (Y[q][c] ^ get32(X, min(max(2 * (16 * c + dd), -32), 32 * D))) & range_mask32(lo - 16 * c, hi - 16 * c);
                         hit[q] = diff == 0;                                         // :607-626 (contained-and-equal counts here)
                         hlen[q] = rightSide ? (L2 - (L1 - j)) : (L2 - j - h);
                         htype[q] = t == 0 ? 3u : (t == 1 ? 0u : (t == 2 ? 2u : 1u));
@@ -1287,7 +1291,7 @@ __global__ __launch_bounds__(64 * WPB, SAGE2OV_FAST_WAVES) void k_probe_fast(Pro
                             else if (t == 2) { dd = L1 - j - L2; lo = L2 - n; hi = L2; } else { dd = j + h - L2; lo = L2 - n; hi = L2; }
                             u32 diff = 0;
 #pragma unroll
-                            for (int c = 0; c < NW; c++) diff |= (Y[q][c] ^ get32z(X, D + 2, 2 * (16 * c + dd))) & range_mask32(lo - 16 * c, hi - 16 * c);
+                            for (int c = 0; c < NW; c++) diff |= (Y[q][c] ^ get32(X, min(max(2 * (16 * c + dd), -32), 32 * D))) & range_mask32(lo - 16 * c, hi - 16 * c);
                             if (diff == 0) {
                                 if (cont) atomicOr(&A.cflag[myEnt[q] >> 2], i > (u64)(myEnt[q] >> 2) ? 1u : 2u);   // economyGraph.cpp:735
                                 else bad = true;                                                    // a true overlap that disagrees with the longest one
@@ -1312,6 +1316,7 @@ __global__ __launch_bounds__(64 * WPB, SAGE2OV_FAST_WAVES) void k_probe_fast(Pro
                 // written, hit by hit in window / bucket order, but on data this wave already holds: every candidate is compared directly with
                 // this read, the overhang of every hit goes to LDS, and one step of the machine is a dword-parallel prefix compare of two overhangs.
                 bool thit[2] = {false, false}; bool tooLong = false;
+                uint8_t* const tailSlot = L.tslotIdx;
 #pragma unroll
                 for (int q = 0; q < 2; q++) {
                     if (q == 1 && !two) continue;
@@ -1336,7 +1341,7 @@ __global__ __launch_bounds__(64 * WPB, SAGE2OV_FAST_WAVES) void k_probe_fast(Pro
                         else if (t == 2) { dd = L1 - j - L2; lo = L2 - n; hi = L2; } else { dd = j + h - L2; lo = L2 - n; hi = L2; }
                         u32 diff = 0;
 #pragma unroll
-                        for (int c = 0; c < NW; c++) diff |= (Y[q][c] ^ get32z(X, D + 2, 2 * (16 * c + dd))) & range_mask32(lo - 16 * c, hi - 16 * c);
+                        for (int c = 0; c < NW; c++) diff |= (Y[q][c] ^ get32(X, min(max(2 * (16 * c + dd), -32), 32 * D))) & range_mask32(lo - 16 * c, hi - 16 * c);
                         if (diff == 0) {
                             if (cont) atomicOr(&A.cflag[myEnt[q] >> 2], i > (u64)(myEnt[q] >> 2) ? 1u : 2u);   // economyGraph.cpp:735
                             else {
@@ -1354,47 +1359,60 @@ __global__ __launch_bounds__(64 * WPB, SAGE2OV_FAST_WAVES) void k_probe_fast(Pro
                             }
                         }
                     }
-                    // (own slot only: the overhang replaces the candidate's dwords)
-                    if (ci < total || q == 0) {
-                        L.candJ[ci] = meta; L.candSrc[ci] = myEnt[q] >> 2;
+                    // the overhang replaces the candidate's dwords in its own slot; geometry, read id and slot of the hits are compacted in
+                    // visiting order (candidate slots are in window / bucket order, so a ballot prefix is the position)
 #pragma unroll
-                        for (int c = 0; c < TAIL_OVW; c++) L.tslot[ci][c] = ovd[c];
+                    for (int c = 0; c < TAIL_OVW; c++) L.tslot[ci][c] = ovd[c];
+                    const u64 hb = __ballot(thit[q]);
+                    if (thit[q]) {
+                        const u32 hx = nhits + (u32)__popcll(hb & ((1ull << lane) - 1ull));
+                        L.candJ[hx] = meta; L.candSrc[hx] = myEnt[q] >> 2; tailSlot[hx] = (uint8_t)ci;
                     }
+                    nhits += (u32)__popcll(hb);
                 }
                 if (__any(tooLong)) slowpath = true;
                 wave_sync();
                 if (!slowpath) {
                     u32 rightId = 0, rightO = 0, leftId = 0, leftO = 0, rightLen = 0, leftLen = 0;
-                    u32 pRi = 0, pLi = 0, pRL = 0, pLL = 0, pRov = 0, pLov = 0;
+                    u32 pRL = 0, pLL = 0, pRov = 0, pLov = 0;
                     bool ambR = false, ambL = false, mAR = false, mAL = false, mFR = false; int curJ = -1;
-                    const u32 nslot = two ? min(total, 128u) : min(total, 64u);
-                    for (u32 x = 0; x < nslot; x++) {
-                        const u32 a = L.candJ[x], r2 = L.candSrc[x];
-                        if (!(a & 0x80000000u)) continue;                               // not a verified hit
-                        nhits++;
+                    // One step = compare the hit's overhang with the overhang of the side's current `prev` over their common length.  The
+                    // prev overhangs stay in registers (lane c < 8 holds dword c of both sides), the next hit's geometry and overhang are
+                    // fetched from LDS one and two steps ahead: the serial chain per hit is a ballot and a few uniform updates.
+                    const u32 lc = lane < (u32)TAIL_OVW ? lane : 0u;
+                    const u32 nh = nhits;
+                    u32 pRw = 0, pLw = 0;                                           // this lane's dword of the right / left prev overhang
+                    u32 a0 = L.candJ[0], r20 = L.candSrc[0], a1 = L.candJ[nh > 1 ? 1 : 0], r21 = L.candSrc[nh > 1 ? 1 : 0];
+                    u32 s1 = tailSlot[nh > 1 ? 1 : 0];
+                    u32 cw0 = L.tslot[tailSlot[0]][lc];
+                    for (u32 x = 0; x < nh; x++) {
+                        const u32 xn = x + 2 < nh ? x + 2 : x;                              // two ahead: geometry, id, slot; one ahead: the overhang dword
+                        const u32 a2 = L.candJ[xn], r22 = L.candSrc[xn], s2 = tailSlot[xn];
+                        const u32 cw1 = L.tslot[s1][lc];
+                        const u32 a = a0, r2 = r20, cw = cw0;
                         const bool isLeft = a & 1u; const u32 o = (a >> 1) & 1u, L2 = (a >> 2) & 0x1FFu, ov = (a >> 20) & 0xFFu; const int jw = (int)((a >> 11) & 0x1FFu);
                         if (jw != curJ) { curJ = jw; mAR = mAL = mFR = false; }
-                        const u32 pi = isLeft ? pLi : pRi, pov = isLeft ? pLov : pRov;
+                        const u32 pov = isLeft ? pLov : pRov, pw = isLeft ? pLw : pRw;
                         const int m = (int)min(pov, ov);
-                        const u32 lc = lane < (u32)TAIL_OVW ? lane : 0u;
-                        const bool dif = lane < (u32)TAIL_OVW && ((L.tslot[pi][lc] ^ L.tslot[x][lc]) & mask_top32(m - 16 * (int)lc)) != 0;
+                        const bool dif = lane < (u32)TAIL_OVW && ((pw ^ cw) & mask_top32(m - 16 * (int)lc)) != 0;
                         const bool cons = !__any(dif);
                         if (!isLeft) {
-                            if (rightId == 0) { rightId = r2; rightO = o; rightLen = ov; pRi = x; pRL = L2; pRov = ov; mAR = true; mFR = true; }
+                            if (rightId == 0) { rightId = r2; rightO = o; rightLen = ov; pRw = cw; pRL = L2; pRov = ov; mAR = true; mFR = true; }
                             else if (cons) {
                                 bool upd = false;
                                 if (mAR) { if (L2 > pRL) { if (mFR) { rightId = r2; rightO = o; rightLen = ov; } upd = true; } }
                                 else { upd = true; mAR = true; }
-                                if (upd) { pRi = x; pRL = L2; pRov = ov; }
+                                if (upd) { pRw = cw; pRL = L2; pRov = ov; }
                             } else ambR = true;
                         } else {
-                            if (leftId == 0) { leftId = r2; leftO = o; leftLen = ov; pLi = x; pLL = L2; pLov = ov; mAL = true; }
+                            if (leftId == 0) { leftId = r2; leftO = o; leftLen = ov; pLw = cw; pLL = L2; pLov = ov; mAL = true; }
                             else if (cons) {
                                 bool upd = false;
                                 if (mAL) { if (L2 > pLL) upd = true; } else { upd = true; mAL = true; }
-                                if (upd) { leftId = r2; leftO = o; leftLen = ov; pLi = x; pLL = L2; pLov = ov; }
+                                if (upd) { leftId = r2; leftO = o; leftLen = ov; pLw = cw; pLL = L2; pLov = ov; }
                             } else ambL = true;
                         }
+                        a0 = a1; r20 = r21; cw0 = cw1; a1 = a2; r21 = r22; s1 = s2;
                     }
                     if (ambR || ambL) { rightLen = 0; leftLen = 0; }                                        // economyGraph.cpp:446-450
                     if (lane == 0) {
