@@ -127,7 +127,11 @@ __device__ __forceinline__ u64 hash_key(u64 hi, u64 lo, int h, u64 seed) {
     else { nh = (hi << sh) | (lo >> (64 - sh)); nl = lo << sh; }
     return hash4((u32)(nh >> 32), (u32)nh, (u32)(nl >> 32), (u32)nl, (u32)seed, 2 * h > 96);
 }
-__device__ __forceinline__ u32 tag_of(u64 hv) { u32 t = (u32)(hv & 0xFFFFFFu); return t ? t : 1u; }
+// 24-bit tag of a key.  g_tag_mask is 0xFFFFFF except in tests, which shrink it (SAGE2OV_TEST_TAG_BITS) so that different keys share
+// tags often: everything that depends on "equal tag and same probe chain => one bucket" then runs thousands of times per data set
+// instead of about once per ten million reads.
+__device__ u32 g_tag_mask = 0xFFFFFFu;
+__device__ __forceinline__ u32 tag_of(u64 hv) { u32 t = (u32)hv & g_tag_mask; return t ? t : 1u; }
 // ---- minimiser index (second access path used by the fast kernel): distinct keys grouped by their minimiser
 // (smallest hashed w-mer of the key, w = min(16,h)).  The ~13 consecutive windows of a read that share a minimiser
 // find their keys in ONE contiguous group instead of 13 random sectors of the uniform table.
@@ -332,7 +336,15 @@ __device__ __forceinline__ void entry_key(const u64* __restrict__ reads, int S, 
 // claiming and counting are one atomic on one word, and the value the atomic returns is the entry's rank inside its bucket
 // (the key's rank inside its group), so the fill kernel needs no cursors.  k_index_alloc / k_mi_alloc rewrite the words
 // into their final form.
-constexpr u64 BUILD_CNT_MASK = (1ull << SLOT_TAG_SHIFT) - 1;
+constexpr u64 BUILD_CNT_MASK = (1ull << SLOT_TAG_SHIFT) - 1;       // group words: mtag:24 | keys so far:40
+// slot words during the build: tag:24 | fingerprint:16 | entries so far:24.  The fingerprint (16 more hash bits) tells a later
+// arrival whether the bucket it joins was claimed by ANOTHER key with the same tag on the same probe chain.  The uniform table
+// wants exactly that merge (one tag, one bucket: look-ups verify every candidate), but the minimiser groups are per key: the
+// arrival then files a second record of the bucket under its own key's minimiser (WHERE_REC), or its windows would never find it.
+constexpr u64 SLOT_BUILD_CNT = (1ull << 24) - 1;
+constexpr int SLOT_FP_SHIFT = 24;
+constexpr u64 WHERE_REC = 1ull << 63;                                // where[e]: this entry writes a group record in the fill kernel
+__device__ __forceinline__ u64 fp_of(u64 hv) { return ((hv >> 24) ^ (hv >> 47)) & 0xFFFFull; }
 __device__ __forceinline__ u64 mi_claim_count(u64* mi1, u64 TL, u32 mh, u32& rank) {
     const u64 mt = minim_tag(mh); u64 idx = __umulhi(mh, (u32)TL);
     for (u32 step = 0; step < 2048u; step++) {
@@ -353,24 +365,29 @@ __global__ void k_index_count(const u64* __restrict__ reads, u64 N, int S, int h
     for (; e < 4 * N; e += stride) {
         u64 hi, lo; entry_key(reads, S, h, (e >> 2) + 1, (int)(e & 3), hi, lo);
         u64 hv = hash_key(hi, lo, h, seed); const u64 tag = tag_of(hv); u64 idx = home_of(hv, T);
-        u64 rank = 0;
+        u64 rank = 0; bool files = false; const u64 fp = fp_of(hv);
         for (;;) {
             u64 s = __hip_atomic_load(&slots[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (s == 0) {
-                s = atomicCAS((u64*)&slots[idx], 0ull, (tag << SLOT_TAG_SHIFT) | 1ull);
-                if (s == 0) break;                                     // claimed: rank 0
+                s = atomicCAS((u64*)&slots[idx], 0ull, (tag << SLOT_TAG_SHIFT) | (fp << SLOT_FP_SHIFT) | 1ull);
+                if (s == 0) { files = true; break; }                   // claimed: rank 0
             }
-            if ((s >> SLOT_TAG_SHIFT) == tag) { rank = atomicAdd((u64*)&slots[idx], 1ull) & BUILD_CNT_MASK; break; }
+            if ((s >> SLOT_TAG_SHIFT) == tag) {
+                rank = atomicAdd((u64*)&slots[idx], 1ull) & SLOT_BUILD_CNT;
+                if (rank >= SLOT_BUILD_CNT - 8) atomicAdd(&micounters[8], 1ull);          // more than 16 M entries under one key: not supported
+                files = ((s >> SLOT_FP_SHIFT) & 0xFFFFull) != fp;      // another key's bucket (same tag, same chain)
+                break;
+            }
             if (++idx == T) idx = 0;
         }
-        where[e] = idx | (rank << 32);                                 // (ranks beyond 2^32 cannot occur: 4N < 2^32 entries)
-        if (whereG && rank == 0) {                                     // one thread per bucket, key still in registers: its minimiser group (stage B)
+        if (whereG && files) {                                         // (at least) one thread per key, key still in registers: its minimiser group (stage B)
             u32 k0, k1, k2, k3; key_left_align(hi, lo, h, k0, k1, k2, k3);
             u32 grank = 0;
             const u64 g = mi_claim_count(mi1, TL, minim_hash(key_min_hash(k0, k1, k2, k3, h), (u32)seed), grank);
             if (g == ~0ull) { atomicAdd(&micounters[7], 1ull); whereG[e] = ~0ull; }
-            else whereG[e] = g | ((u64)grank << 32);                   // read back by the same entry (rank 0) in the fill kernel: a stream, not a gather
+            else whereG[e] = g | ((u64)grank << 32);                   // read back by the same entry in the fill kernel: a stream, not a gather
         }
+        where[e] = idx | (rank << 32) | (files ? WHERE_REC : 0ull);    // (ranks stay below 2^24)
     }
 }
 __global__ void k_debug_table(const u64* __restrict__ slots, u64 T, u64* out) {
@@ -401,7 +418,7 @@ __global__ __launch_bounds__(256) void k_index_alloc(u64* slots, u64 T, u64* cou
 #pragma unroll
     for (int x = 0; x < ALLOC_PER_THREAD; x++) {
         const u64 idx = base0 + (u64)x * 256 + threadIdx.x;
-        c[x] = idx < T ? (u32)(slots[idx] & BUILD_CNT_MASK) : 0u;
+        c[x] = idx < T ? (u32)(slots[idx] & SLOT_BUILD_CNT) : 0u;
         need += c[x] >= 2 ? c[x] : 0u; occ += c[x] != 0;
     }
     u32 total; u32 excl = block_excl_scan(need, sh, total);
@@ -429,13 +446,13 @@ __global__ void k_index_fill(u64 N, u64* slots, const u64* __restrict__ where, u
     u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     const u64 stride = (u64)gridDim.x * blockDim.x;
     for (; e < 4 * N; e += stride) {
-        const u64 wv = where[e]; const u64 idx = wv & 0xFFFFFFFFull; const u32 rank = (u32)(wv >> 32);
+        const u64 wv = where[e]; const u64 idx = wv & 0xFFFFFFFFull; const u32 rank = (u32)(wv >> 32) & 0x7FFFFFFFu;
         u64 s = slots[idx];
         const u32 c7 = (u32)(s >> SLOT_CNT_SHIFT) & 127u;
         const u32 entry = (u32)(((e >> 2) + 1) * 4 + (e & 3));
         if (c7 == 0) { s = (s & (~0ull << SLOT_TAG_SHIFT)) | (1ull << SLOT_CNT_SHIFT) | entry; slots[idx] = s; }   // the only entry: inline
         else csr[(s & SLOT_PAY_MASK) + rank] = entry;
-        if (whereG && rank == 0) {                                     // one entry per bucket: the bucket's record goes into its minimiser group (stage B)
+        if (whereG && (wv & WHERE_REC)) {                              // one entry per key: the bucket's record goes into the key's minimiser group (stage B)
             const u64 sg = whereG[e];
             if (sg != ~0ull) {
                 const u64 v = mi1[(u32)sg];
@@ -485,6 +502,22 @@ __global__ __launch_bounds__(256) void k_mi_alloc(u64* mi1, u64 TL, u64* counter
             start += c[x];
         }
     }
+}
+// self-check of the minimiser groups (SAGE2OV_VERIFY_MI): every entry's key must find, in the group of its own minimiser, a record that
+// is the word of the slot the entry went to.  counters: [0] entries without such a record, [1] entries checked
+__global__ void k_mi_verify(const u64* __restrict__ reads, u64 N, int S, int h, u64 seed, const u64* __restrict__ slots, const u64* __restrict__ where,
+                            const u64* __restrict__ mi1, u64 TL, const u64* __restrict__ krec, u64* out) {
+    const u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x; if (e >= 4 * N) return;
+    u64 hi, lo; entry_key(reads, S, h, (e >> 2) + 1, (int)(e & 3), hi, lo);
+    u32 k0, k1, k2, k3; key_left_align(hi, lo, h, k0, k1, k2, k3);
+    const u32 mh = minim_hash(key_min_hash(k0, k1, k2, k3, h), (u32)seed); const u64 mt = minim_tag(mh);
+    u64 idx = __umulhi(mh, (u32)TL); u64 gv = 0;
+    for (u32 step = 0; step < 4096u; step++) { gv = mi1[idx]; if (gv == 0 || (gv >> SLOT_TAG_SHIFT) == mt) break; if (++idx == TL) idx = 0; }
+    const u64 want = slots[where[e] & 0xFFFFFFFFull];
+    bool ok = false;
+    if (gv != 0) { const u32 n = (u32)(gv >> 32) & 255u, st = (u32)gv; if (n == MI_BIG) ok = true; else for (u32 x = 0; x < n; x++) if (krec[st + x] == want) ok = true; }
+    atomicAdd(&out[1], 1ull);
+    if (!ok) { if (atomicAdd(&out[0], 1ull) < 8) printf("[verify-mi] e=%llu where=%llx want=%llx gv=%llx fp=%llx\n", (unsigned long long)e, (unsigned long long)where[e], (unsigned long long)want, (unsigned long long)gv, (unsigned long long)fp_of(hash_key(hi, lo, h, seed))); }
 }
 __global__ void k_lookup(const u64* __restrict__ slots, u64 T, const u32* __restrict__ csr, u64 seed, int h, u64 hi, u64 lo, u64* out, u32 cap) {
     u64 s = table_find(slots, T, hash_key(hi, lo, h, seed));
@@ -1761,9 +1794,12 @@ Device* dev_create(int ordinal, std::string& err) {
     if (hipSetDevice(dev) != hipSuccess) { err = "hipSetDevice failed"; return nullptr; }
     Device* d = new Device(); d->ordinal = dev;
     if (hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess) { err = "hipStreamCreate failed"; delete d; return nullptr; }
+    { const char* tb = getenv("SAGE2OV_TEST_TAG_BITS"); const int nb = tb ? atoi(tb) : 24;
+      const u32 mask = (nb >= 1 && nb < 24) ? ((1u << nb) - 1u) : 0xFFFFFFu;
+      if (hipMemcpyToSymbol(HIP_SYMBOL(g_tag_mask), &mask, sizeof mask) != hipSuccess) { err = "tag mask upload failed"; delete d; return nullptr; } }
     for (auto& ev : d->ev) hipEventCreate(&ev);
-    if (hipMalloc(&d->d_counters, 16 * sizeof(u64)) != hipSuccess) { err = "hipMalloc(counters) failed"; delete d; return nullptr; }
-    hipMemset(d->d_counters, 0, 16 * sizeof(u64));
+    if (hipMalloc(&d->d_counters, 24 * sizeof(u64)) != hipSuccess) { err = "hipMalloc(counters) failed"; delete d; return nullptr; }
+    hipMemset(d->d_counters, 0, 24 * sizeof(u64));
     return d;
 }
 static void free_reads(Device* d) {
@@ -1888,7 +1924,7 @@ int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t
     *rebuilds = 0;
     for (int attempt = 0;; attempt++) {
         HIPCHK(hipMemsetAsync(d->slots, 0, d->T * sizeof(u64), d->stream));
-        HIPCHK(hipMemsetAsync(d->d_counters + 8, 0, 8 * sizeof(u64), d->stream));
+        HIPCHK(hipMemsetAsync(d->d_counters + 8, 0, 9 * sizeof(u64), d->stream));
         if (wantMI) HIPCHK(hipMemsetAsync(mi1, 0, TL * sizeof(u64), d->stream));
         const unsigned gE = (unsigned)std::min<u64>(grid_for(4 * N, 256), 256 * 64);
         hipLaunchKernelGGL(k_index_count, dim3(gE), dim3(256), 0, d->stream, d->reads, N, d->S, d->h, d->seed, d->slots, d->T, where,
@@ -1897,13 +1933,14 @@ int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t
         if (wantMI) hipLaunchKernelGGL(k_mi_alloc, dim3(grid_for(TL, ALLOC_ITEMS)), dim3(256), 0, d->stream, mi1, TL, d->d_counters + 8);
         hipLaunchKernelGGL(k_index_fill, dim3(gE), dim3(256), 0, d->stream, N, d->slots, where, d->csr, slot_g, mi1, krec);
         hipLaunchKernelGGL(k_index_sort, dim3(grid_for(d->T, 256)), dim3(256), 0, d->stream, d->slots, d->T, d->csr);
-        u64 c[5];
+        u64 c[9];
         HIPCHK(hipMemcpyAsync(c, d->d_counters + 8, sizeof c, hipMemcpyDeviceToHost, d->stream));
         HIPCHK(hipStreamSynchronize(d->stream));
+        if (c[8]) { err = "a key occurs in more than 16 M reads"; return SAGE2OV_ERR_LIMIT; }
         if (c[2] > big_cap) { err = "too many long buckets"; return SAGE2OV_ERR_LIMIT; }
         if (c[2]) {
             hipLaunchKernelGGL(k_index_purity, dim3(grid_for(c[2] * 64, 256)), dim3(256), 0, d->stream, d->reads, d->S, d->h, big, c[2], d->csr, d->d_counters + 8);
-            HIPCHK(hipMemcpyAsync(c, d->d_counters + 8, sizeof c, hipMemcpyDeviceToHost, d->stream));
+            HIPCHK(hipMemcpyAsync(c, d->d_counters + 8, 5 * sizeof(u64), hipMemcpyDeviceToHost, d->stream));
             HIPCHK(hipStreamSynchronize(d->stream));
         }
         if (c[3] == 0) { d->n_csr = c[0]; d->n_keys = c[1]; d->n_long = c[2]; break; }
@@ -1913,11 +1950,19 @@ int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t
     // ---- stage B: minimiser groups over the distinct-key records
     d->mi1 = nullptr; d->krec = nullptr; d->TL = 0;
     if (wantMI && d->n_keys > 0) {
-        HIPCHK(hipMemsetAsync(krec + d->n_keys, 0, MI_SCAN_PAD * sizeof(u64), d->stream));   // the probe scan may run past the last group: empty records
         u64 mc[3];
         HIPCHK(hipMemcpyAsync(mc, d->d_counters + 8 + 5, sizeof mc, hipMemcpyDeviceToHost, d->stream));
         HIPCHK(hipStreamSynchronize(d->stream));
+        // the probe scan may run past the last group: empty records behind ALL records (there are a few more records than slots
+        // when different keys share a bucket: each key files its own copy)
+        HIPCHK(hipMemsetAsync(krec + mc[0], 0, MI_SCAN_PAD * sizeof(u64), d->stream));
         d->n_groups = mc[1];
+        if (getenv("SAGE2OV_VERIFY_MI")) {
+            u64* vo = nullptr; HIPCHK(hipMalloc(&vo, 2 * sizeof(u64))); HIPCHK(hipMemsetAsync(vo, 0, 2 * sizeof(u64), d->stream));
+            hipLaunchKernelGGL(k_mi_verify, dim3(grid_for(4 * N, 256)), dim3(256), 0, d->stream, d->reads, N, d->S, d->h, d->seed, d->slots, where, mi1, TL, krec, vo);
+            u64 hv2[2]; HIPCHK(hipMemcpyAsync(hv2, vo, sizeof hv2, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream)); hipFree(vo);
+            fprintf(stderr, "[verify-mi] %llu of %llu entries do not find their bucket in their key's group\n", (unsigned long long)hv2[0], (unsigned long long)hv2[1]);
+        }
         if (mc[2] == 0 && mc[1] * 10 <= TL * 7) { d->mi1 = mi1; d->krec = krec; d->TL = TL; }   // else: too crowded, the fast kernel uses the uniform table
     }
     HIPCHK(hipEventRecord(d->ev[1], d->stream));

@@ -406,3 +406,22 @@ def test_high_coverage_many_candidates_match_oracle(reduce_path):
     st = g.overlap_stats()
     assert (st.edges_inserted, st.transitive_removed) == (o.counter("edges_inserted"), o.counter("transitive_removed"))
     g.close(); o.close()
+
+
+@pytest.mark.parametrize("bits", [10, 14])
+def test_tag_collisions_are_harmless(bits, monkeypatch):
+    """Two different keys with the same 24-bit tag on one probe chain share a bucket (about once per ten million reads).  With the tag
+    cut to 10-14 bits that happens thousands of times in a small data set: merged buckets in the uniform table, their records in the
+    minimiser groups of BOTH keys, ambiguous tags inside a group -- and the results must not move."""
+    monkeypatch.setenv("SAGE2OV_TEST_TAG_BITS", str(bits))
+    pd = dict(seed=41, genome_len=120000, n_reads=40000, read_len=150, err_ppm=500)
+    bases, off = fx.make_reads(pd)
+    m = dict(k=40)
+    g, o = run_gpu(m, bases, off), run_oracle(m, bases, off)
+    assert g.index_stats().keys < o.counter("keys"), "the shrunken tags are meant to merge buckets"
+    gr, gl, gs, gc = g.overlap_export_initial(); orr, orl, ors, orc = o.export_initial()
+    assert np.array_equal(gc, orc) and np.array_equal(gr[1:], orr[1:]) and np.array_equal(gl[1:], orl[1:])
+    e, oe = g.edges(), o.export_edges()
+    assert len(e) == len(oe) and np.array_equal(e["from"], oe[:, 0]) and np.array_equal(e["to"], oe[:, 1])
+    assert np.array_equal(e["type"], oe[:, 2]) and np.array_equal(e["length"], oe[:, 3]) and np.array_equal(e["length_twin"], oe[:, 4])
+    g.close(); o.close()
