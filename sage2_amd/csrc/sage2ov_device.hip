@@ -138,7 +138,8 @@ __device__ __forceinline__ u32 tag_of(u64 hv) { u32 t = (u32)hv & g_tag_mask; re
 __device__ __forceinline__ u32 mix32(u32 x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
 __device__ __forceinline__ u32 wmer_hash(u32 wm) { wm *= 0x9E3779B1u; return wm ^ (wm >> 15); }        // order of w-mers (one multiply)
 __device__ __forceinline__ u32 minim_hash(u32 minh, u32 seed) { return mix32(minh ^ (seed * 0x85EBCA77u + 0x165667B1u)); }   // uniform 32 bits
-__device__ __forceinline__ u32 minim_tag(u32 mh) { u32 t = mix32(mh + 0x2545F491u) & 0xFFFFFFu; return t ? t : 1u; }
+__device__ u32 g_mtag_mask = 0xFFFFFFu;          // tests shrink it (SAGE2OV_TEST_MTAG_BITS): groups of different minimisers then merge often
+__device__ __forceinline__ u32 minim_tag(u32 mh) { u32 t = mix32(mh + 0x2545F491u) & g_mtag_mask; return t ? t : 1u; }
 __device__ __forceinline__ u32 funnel32k(u32 a, u32 b, int r) { return (u32)(((((u64)a) << 32) | b) >> (32 - r)); }
 // smallest w-mer hash of a left-aligned h-base key (dwords k0..k3)
 __device__ __forceinline__ u32 key_min_hash(u32 k0, u32 k1, u32 k2, u32 k3, int h) {
@@ -1796,7 +1797,10 @@ Device* dev_create(int ordinal, std::string& err) {
     if (hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess) { err = "hipStreamCreate failed"; delete d; return nullptr; }
     { const char* tb = getenv("SAGE2OV_TEST_TAG_BITS"); const int nb = tb ? atoi(tb) : 24;
       const u32 mask = (nb >= 1 && nb < 24) ? ((1u << nb) - 1u) : 0xFFFFFFu;
-      if (hipMemcpyToSymbol(HIP_SYMBOL(g_tag_mask), &mask, sizeof mask) != hipSuccess) { err = "tag mask upload failed"; delete d; return nullptr; } }
+      if (hipMemcpyToSymbol(HIP_SYMBOL(g_tag_mask), &mask, sizeof mask) != hipSuccess) { err = "tag mask upload failed"; delete d; return nullptr; }
+      const char* mb = getenv("SAGE2OV_TEST_MTAG_BITS"); const int nm = mb ? atoi(mb) : 24;
+      const u32 mmask = (nm >= 1 && nm < 24) ? ((1u << nm) - 1u) : 0xFFFFFFu;
+      if (hipMemcpyToSymbol(HIP_SYMBOL(g_mtag_mask), &mmask, sizeof mmask) != hipSuccess) { err = "tag mask upload failed"; delete d; return nullptr; } }
     for (auto& ev : d->ev) hipEventCreate(&ev);
     if (hipMalloc(&d->d_counters, 24 * sizeof(u64)) != hipSuccess) { err = "hipMalloc(counters) failed"; delete d; return nullptr; }
     hipMemset(d->d_counters, 0, 24 * sizeof(u64));

@@ -408,6 +408,22 @@ def test_high_coverage_many_candidates_match_oracle(reduce_path):
     g.close(); o.close()
 
 
+@pytest.mark.parametrize("mbits", [6, 12])
+def test_group_tag_collisions_are_harmless(mbits, monkeypatch):
+    """Minimiser groups are found by a 24-bit tag of the minimiser: with 6-12 bits different minimisers share a group word (a group is
+    then a superset, possibly oversized -> uniform table).  Results must not move; the device self-check must hold."""
+    monkeypatch.setenv("SAGE2OV_TEST_MTAG_BITS", str(mbits))
+    pd = dict(seed=43, genome_len=120000, n_reads=40000, read_len=150, err_ppm=500)
+    bases, off = fx.make_reads(pd)
+    m = dict(k=40)
+    g, o = run_gpu(m, bases, off), run_oracle(m, bases, off)
+    gr, gl, gs, gc = g.overlap_export_initial(); orr, orl, ors, orc = o.export_initial()
+    assert np.array_equal(gc, orc) and np.array_equal(gr[1:], orr[1:]) and np.array_equal(gl[1:], orl[1:])
+    e, oe = g.edges(), o.export_edges()
+    assert len(e) == len(oe) and np.array_equal(e["from"], oe[:, 0]) and np.array_equal(e["to"], oe[:, 1]) and np.array_equal(e["length"], oe[:, 3])
+    g.close(); o.close()
+
+
 @pytest.mark.parametrize("bits", [10, 14])
 def test_tag_collisions_are_harmless(bits, monkeypatch):
     """Two different keys with the same 24-bit tag on one probe chain share a bucket (about once per ten million reads).  With the tag
