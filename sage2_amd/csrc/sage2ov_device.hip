@@ -2254,6 +2254,7 @@ int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved
         WS(slow, u32, WS_SLOW, N + 1);
         const unsigned blocks = (unsigned)std::min<u64>((N + FAST_CHUNK - 1) / FAST_CHUNK, 256ull * 16);
         u64 cap = std::max<u64>(1 << 16, nun * 80) + (u64)blocks * SAGE2OV_FAST_WPB * HITS_CHUNK; bool ok = false;
+        if (getenv("SAGE2OV_TEST_SMALL_BUFFERS")) cap = 8192;                      // tests: start far too small, the sizing loop must recover
         for (int attempt = 0; attempt < 4 && !ok; attempt++) {
             WS(hb, Hit, WS_HITS, cap); dh = hb;
             HIPCHK(hipMemsetAsync(d->d_counters + 4, 0, 3 * sizeof(u64), d->stream));
@@ -2300,7 +2301,7 @@ int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved
     HIPCHK(hipMemcpyAsync(c, d->d_counters + 8, sizeof c, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
     HIPCHK(hipGetLastError());
     if (c[0] != 0) return 0;                                              // a list does not fit the device kernel: serial replay
-    if (d->n_cand + nsv > d->cand_cap) {
+    if (d->n_cand + nsv > d->cand_cap || getenv("SAGE2OV_TEST_SMALL_BUFFERS")) {
         EdgeCand* ncand = nullptr; const u64 ncap = d->n_cand + nsv + 1024;
         HIPCHK(hipMalloc(&ncand, ncap * sizeof(EdgeCand)));
         HIPCHK(hipMemcpyAsync(ncand, d->cand, d->n_cand * sizeof(EdgeCand), hipMemcpyDeviceToDevice, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));

@@ -457,3 +457,19 @@ def test_impure_long_buckets_trigger_reseed_and_result_is_unchanged(monkeypatch,
     gp = str(tmp_path / "t.graph3"); ctx.graph_save(gp)
     assert open(gp, "rb").read() == fx.golden_graph3(name)
     ctx.close()
+
+
+def test_undersized_device_buffers_are_regrown(monkeypatch):
+    """The hit buffer of the device reduce is sized from an estimate and retried when a wave's chunk does not fit; the candidate list is
+    regrown when the survivors do not fit.  SAGE2OV_TEST_SMALL_BUFFERS starts both far too small."""
+    monkeypatch.setenv("SAGE2OV_TEST_SMALL_BUFFERS", "1")
+    monkeypatch.setenv("SAGE2OV_DEVICE_REDUCE_MIN", "1")
+    pd = dict(seed=1003, genome_len=160000, n_reads=80000, read_len=100, err_ppm=1500, n_repeat_families=3, repeat_copies=6, repeat_len=400)
+    bases, off = fx.make_reads(pd)
+    m = dict(k=21)
+    g, o = run_gpu(m, bases, off), run_oracle(m, bases, off)
+    e, oe = g.edges(), o.export_edges()
+    assert len(e) == len(oe) and np.array_equal(e["from"], oe[:, 0]) and np.array_equal(e["to"], oe[:, 1]) and np.array_equal(e["length"], oe[:, 3])
+    st = g.overlap_stats()
+    assert (st.edges_inserted, st.transitive_removed) == (o.counter("edges_inserted"), o.counter("transitive_removed"))
+    g.close(); o.close()
