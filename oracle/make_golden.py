@@ -31,6 +31,8 @@ FIXTURES = {
                                       n_repeat_families=1, repeat_copies=500, repeat_len=150)),
     "g5_mixedlen_k21":   (21, 1, dict(seed=5, genome_len=40000, n_reads=24000, read_len=100, read_len_min=70, err_ppm=2000)),
     "g6_k70_150":        (70, 8, dict(seed=6, genome_len=60000, n_reads=20000, read_len=150, err_ppm=1000)),
+    # hand-made input (tests/fixtures.py::recipe_reads): palindromic region, tandem repeat, mirrored duplicates
+    "g7_palindrome_tandem_k21": (21, 8, dict(recipe="palindrome_tandem", seed=7, half=700, flank=24000, tandem_units=60, read_len=100, step=3)),
 }
 
 def md5(path):
@@ -62,8 +64,14 @@ def main():
         if only and name not in only: continue
         tmp = tempfile.mkdtemp(prefix="sage2gold_")
         try:
-            p = SynthParams(**pd); fa = os.path.join(tmp, "x.fa")
-            assert lib.sage2ov_synth_write_fasta(ctypes.byref(p), fa.encode()) == 0
+            fa = os.path.join(tmp, "x.fa")
+            if "recipe" in pd:
+                sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
+                import fixtures
+                fixtures.write_recipe_fasta(pd, fa)
+            else:
+                p = SynthParams(**pd)
+                assert lib.sage2ov_synth_write_fasta(ctypes.byref(p), fa.encode()) == 0
             env = dict(os.environ, OMP_NUM_THREADS=str(threads), LC_ALL="C")
             subprocess.run([REF, "-f", fa, "-k", str(k), "-o", os.path.join(tmp, "out"), "-p", "t", "-M", "3", "-s"], check=True, env=env,
                            stdout=subprocess.DEVNULL)

@@ -35,8 +35,40 @@ def synth_params(d) -> s2.SynthParams:
     return s2.SynthParams(**d)
 
 
+def recipe_reads(pd):
+    """Hand-made inputs the generator never produces (dict with a "recipe" key) -> list of read strings.
+    palindrome_tandem: a genome that is its own reverse complement around a centre (reads at mirrored positions share a canonical
+    form; reads across the centre equal their own reverse complement), a tandem repeat of period 7 (several overlaps per read pair,
+    a read's prefix equal to its own later windows), embedded in random sequence long enough for the reference (> 12.5 k unique reads)."""
+    import numpy as np
+    assert pd["recipe"] == "palindrome_tandem"
+    rng = np.random.default_rng(pd["seed"])
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    def rc(s): return "".join(comp[c] for c in reversed(s))
+    def rnd(n): return "".join(rng.choice(list("ACGT"), size=n))
+    half = rnd(pd["half"])
+    genome = rnd(pd["flank"]) + half + rc(half) + rnd(200) + "ACGTTGA" * pd["tandem_units"] + rnd(pd["flank"])
+    L, step, reads = pd["read_len"], pd["step"], []
+    for i, p0 in enumerate(range(0, len(genome) - L + 1, step)):
+        s = genome[p0:p0 + L]
+        reads.append(s if i % 2 == 0 else rc(s))
+    return reads
+
+
+def write_recipe_fasta(pd, path):
+    with open(path, "w") as f:
+        for i, r in enumerate(recipe_reads(pd)):
+            f.write(">r%d\n%s\n" % (i, r))
+
+
 def make_reads(pd):
     """(bases u8 array, offsets u64 array) of the synthetic data set described by dict pd."""
+    if "recipe" in pd:
+        import numpy as np
+        reads = recipe_reads(pd)
+        bases = np.frombuffer("".join(reads).encode(), dtype=np.uint8).copy()
+        off = np.zeros(len(reads) + 1, dtype=np.uint64); off[1:] = np.cumsum([len(r) for r in reads])
+        return bases, off
     p = synth_params(pd)
     g = s2.synth_genome(p)
     return s2.synth_reads_ascii(p, g)

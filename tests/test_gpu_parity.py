@@ -473,3 +473,29 @@ def test_undersized_device_buffers_are_regrown(monkeypatch):
     st = g.overlap_stats()
     assert (st.edges_inserted, st.transitive_removed) == (o.counter("edges_inserted"), o.counter("transitive_removed"))
     g.close(); o.close()
+
+
+def test_palindromic_and_self_overlapping_reads_match_oracle():
+    """Hand-made corner of the input space the generator never reaches: a genome that is its own reverse complement around its centre
+    (reads at mirrored positions have the same canonical form; reads across the centre equal their own reverse complement), plus a
+    tandem repeat with period 7 (a read overlaps its neighbours at several offsets, and its own prefix equals its own suffix window)."""
+    rng = np.random.default_rng(7)
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    def rc(s): return "".join(comp[c] for c in reversed(s))
+    half = "".join(rng.choice(list("ACGT"), size=700))
+    genome = half + rc(half) + "".join(rng.choice(list("ACGT"), size=200)) + "ACGTTGA" * 60 + "".join(rng.choice(list("ACGT"), size=300))
+    L, k, reads = 100, 21, []
+    for p in range(0, len(genome) - L + 1, 3):
+        s = genome[p:p + L]
+        reads.append(s if (p // 3) % 2 == 0 else rc(s))
+    bases = np.frombuffer("".join(reads).encode(), dtype=np.uint8).copy()
+    off = np.arange(0, (len(reads) + 1) * L, L, dtype=np.uint64)
+    m = dict(k=k)
+    g, o = run_gpu(m, bases, off), run_oracle(m, bases, off)
+    assert g.reads_stats().unique_reads == o.counter("N")
+    gr, gl, gs, gc = g.overlap_export_initial(); orr, orl, ors, orc = o.export_initial()
+    assert np.array_equal(gc, orc) and np.array_equal(gr[1:], orr[1:]) and np.array_equal(gl[1:], orl[1:])
+    e, oe = g.edges(), o.export_edges()
+    assert len(e) == len(oe) and np.array_equal(e["from"], oe[:, 0]) and np.array_equal(e["to"], oe[:, 1])
+    assert np.array_equal(e["type"], oe[:, 2]) and np.array_equal(e["length"], oe[:, 3]) and np.array_equal(e["length_twin"], oe[:, 4])
+    g.close(); o.close()
