@@ -499,3 +499,38 @@ def test_palindromic_and_self_overlapping_reads_match_oracle():
     assert len(e) == len(oe) and np.array_equal(e["from"], oe[:, 0]) and np.array_equal(e["to"], oe[:, 1])
     assert np.array_equal(e["type"], oe[:, 2]) and np.array_equal(e["length"], oe[:, 3]) and np.array_equal(e["length_twin"], oe[:, 4])
     g.close(); o.close()
+
+
+@pytest.mark.parametrize("k", [16, 17, 24, 32, 33, 48, 49, 63, 64, 65])
+def test_key_width_boundaries_match_oracle(k):
+    """Key widths around the word boundaries of the packed key (32 / 48 / 64 bases: 2, 3, 4 dwords, one or two hash rounds, h = min(k, 64))
+    and around the shortest keys that still use the minimiser groups (h - 16 + 1 >= 8)."""
+    pd = dict(seed=50 + k, genome_len=50000, n_reads=16000, read_len=150, err_ppm=800)
+    bases, off = fx.make_reads(pd)
+    m = dict(k=k)
+    g, o = run_gpu(m, bases, off), run_oracle(m, bases, off)
+    assert g.index_stats().keys == o.counter("keys")
+    gr, gl, gs, gc = g.overlap_export_initial(); orr, orl, ors, orc = o.export_initial()
+    assert np.array_equal(gc, orc) and np.array_equal(gr[1:], orr[1:]) and np.array_equal(gl[1:], orl[1:])
+    e, oe = g.edges(), o.export_edges()
+    assert len(e) == len(oe) and np.array_equal(e["from"], oe[:, 0]) and np.array_equal(e["to"], oe[:, 1])
+    assert np.array_equal(e["type"], oe[:, 2]) and np.array_equal(e["length"], oe[:, 3]) and np.array_equal(e["length_twin"], oe[:, 4])
+    g.close(); o.close()
+
+
+@pytest.mark.parametrize("L", [120, 121, 160, 161, 248, 249])
+def test_read_length_layout_boundaries_match_oracle(L):
+    """Longest read exactly at / one past the limits of the read-store layouts: 120 (4 words per read), 160 (8 words, 10-dword compares and
+    the in-kernel state machine), 248 (8 words, 16-dword compares), 249+ (16 words: sequential kernel).  Mixed lengths below it."""
+    pd = dict(seed=70 + L, genome_len=40000, n_reads=12000, read_len=L, read_len_min=L - 40, err_ppm=1000)
+    bases, off = fx.make_reads(pd)
+    m = dict(k=31)
+    g, o = run_gpu(m, bases, off), run_oracle(m, bases, off)
+    gr, gl, gs, gc = g.overlap_export_initial(); orr, orl, ors, orc = o.export_initial()
+    assert np.array_equal(gc, orc) and np.array_equal(gr[1:], orr[1:]) and np.array_equal(gl[1:], orl[1:])
+    e, oe = g.edges(), o.export_edges()
+    assert len(e) == len(oe) and np.array_equal(e["from"], oe[:, 0]) and np.array_equal(e["to"], oe[:, 1])
+    assert np.array_equal(e["type"], oe[:, 2]) and np.array_equal(e["length"], oe[:, 3]) and np.array_equal(e["length_twin"], oe[:, 4])
+    gp, gl_, gf = g.reads_export(); op, ol_, of = o.export_reads()
+    assert np.array_equal(gl_, ol_) and np.array_equal(gf, of)
+    g.close(); o.close()
