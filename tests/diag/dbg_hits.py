@@ -1,5 +1,5 @@
 import sys, os, json
-R=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, R+'/tests')
+R=os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, R); sys.path.insert(0, R+'/tests')
 import fixtures as fx, sage2_amd as s2, oracle_lib as ol, numpy as np
 m = json.loads(sys.argv[1])
 bases, off = fx.make_reads(m["synth"])

@@ -1,7 +1,7 @@
 """diagnostic: per-read connection counts against the oracle with shrunken tags, in several probe modes"""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..")); sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 import fixtures as fx, oracle_lib as ol, sage2_amd as s2
 bits = sys.argv[1] if len(sys.argv) > 1 else "10"
 os.environ["SAGE2OV_TEST_TAG_BITS"] = bits
