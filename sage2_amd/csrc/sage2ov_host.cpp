@@ -14,6 +14,7 @@
 #include <unordered_map>
 #include <vector>
 #include <omp.h>
+#include <sched.h>
 #include "sage2ov.h"
 #include "sage2ov_internal.h"
 
@@ -99,42 +100,94 @@ inline void canonicalise_words(uint64_t* f, int L) {        // readLoader.cpp:19
     for (int w = 0; w < nw; w++) { if (f[w] != r[w]) { useF = f[w] < r[w]; break; } }
     if (!useF) for (int w = 0; w < nw; w++) f[w] = r[w];
 }
+// worker threads of the host-side I/O helpers: the configured number, else what OpenMP and the CPU affinity allow, at most 16
+// (many short parallel regions on an oversubscribed CPU share cost more than they give)
+static int io_threads(const sage2ov_ctx* c) {
+    if (c->cfg.host_threads) return (int)c->cfg.host_threads;
+    int nt = omp_get_max_threads();
+    cpu_set_t set; CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof set, &set) == 0) nt = std::min(nt, CPU_COUNT(&set));
+    return std::max(1, std::min(nt, 16));
+}
 static uint8_t g_code[256];
 struct CodeInit { CodeInit() { memset(g_code, 255, 256); g_code['A'] = g_code['a'] = 0; g_code['C'] = g_code['c'] = 1; g_code['G'] = g_code['g'] = 2; g_code['T'] = g_code['t'] = 3; } } g_code_init;
 
 // minimal FASTA/FASTQ(.gz) record reader with kseq-like rules (fastAQReader.cpp:16-45)
 struct SeqFile {
-    gzFile fp = nullptr; std::vector<char> buf; size_t pos = 0, end = 0; bool eof = false; int pending = -2;
-    bool open(const char* p) { fp = gzopen(p, "r"); buf.resize(1 << 20); return fp != nullptr; }
+    gzFile fp = nullptr; std::vector<char> buf; size_t pos = 0, end = 0; bool eof = false;
+    bool open(const char* p) { fp = gzopen(p, "r"); if (fp) gzbuffer(fp, 1 << 20); buf.resize(8 << 20); return fp != nullptr; }
     ~SeqFile() { if (fp) gzclose(fp); }
-    int getc_() { if (pos >= end) { if (eof) return -1; int n = gzread(fp, buf.data(), (unsigned)buf.size()); if (n <= 0) { eof = true; return -1; } end = n; pos = 0; } return (unsigned char)buf[pos++]; }
-    bool line(std::string& s) { s.clear(); int ch; bool any = false; while ((ch = getc_()) >= 0) { any = true; if (ch == '\n') break; s.push_back((char)ch); } if (!s.empty() && s.back() == '\r') s.pop_back(); return any; }
-    std::string held; bool haveHeld = false;
-    bool next(std::string& seq) {
-        std::string l; seq.clear();
-        for (;;) { if (haveHeld) { l = held; haveHeld = false; } else if (!line(l)) return false; if (!l.empty() && (l[0] == '>' || l[0] == '@')) break; }
+    bool refill() { if (eof) return false; int n = gzread(fp, buf.data(), (unsigned)buf.size()); if (n <= 0) { eof = true; return false; } end = (size_t)n; pos = 0; return true; }
+    // next line (without the line end) appended to `s`; lines are found with memchr on the 8 MB window
+    bool line(std::string& s) {
+        s.clear(); bool any = false;
         for (;;) {
-            if (!line(l)) return true;
-            if (!l.empty() && (l[0] == '>' || l[0] == '@')) { held = l; haveHeld = true; return true; }
-            if (!l.empty() && l[0] == '+') break;
-            for (char ch : l) if (ch > ' ') seq.push_back(ch);
+            if (pos >= end && !refill()) break;
+            any = true;
+            const char* b = buf.data() + pos; const char* nl = (const char*)memchr(b, '\n', end - pos);
+            if (nl) { s.append(b, (size_t)(nl - b)); pos = (size_t)(nl - buf.data()) + 1; break; }
+            s.append(b, end - pos); pos = end;
         }
-        size_t q = 0; while (q < seq.size()) { if (!line(l)) break; q += l.size(); }      // quality: as many characters as bases
+        if (!s.empty() && s.back() == '\r') s.pop_back();
+        return any;
+    }
+    std::string held, l; bool haveHeld = false;
+    // bases of the next record appended to `out` (white space dropped); false at end of file
+    bool next(std::string& out, size_t& len) {
+        const size_t start = out.size();
+        for (;;) { if (haveHeld) { l.swap(held); haveHeld = false; } else if (!line(l)) return false; if (!l.empty() && (l[0] == '>' || l[0] == '@')) break; }
+        for (;;) {
+            if (!line(l)) { len = out.size() - start; return true; }
+            if (!l.empty() && (l[0] == '>' || l[0] == '@')) { held.swap(l); haveHeld = true; len = out.size() - start; return true; }
+            if (!l.empty() && l[0] == '+') break;
+            const size_t at = out.size(); out.append(l);                      // (white space inside a sequence line is rare: compact only then)
+            bool ws = false; for (size_t x = at; x < out.size(); x++) ws |= (unsigned char)out[x] <= ' ';
+            if (ws) { size_t w = at; for (size_t x = at; x < out.size(); x++) if ((unsigned char)out[x] > ' ') out[w++] = out[x]; out.resize(w); }
+        }
+        len = out.size() - start;
+        size_t q = 0; while (q < len) { if (!line(l)) break; q += l.size(); }          // quality: as many characters as bases
         return true;
     }
 };
 
+// records are split sequentially (cheap: memchr), filtered and packed by all threads in batches
 int add_files(sage2ov_ctx* c, const char* p1, const char* p2) {
     SeqFile f1, f2; if (!f1.open(p1)) return c->fail(SAGE2OV_ERR_IO, std::string("cannot open ") + p1);
     const bool two = p2 && *p2; if (two && !f2.open(p2)) return c->fail(SAGE2OV_ERR_IO, std::string("cannot open ") + p2);
-    std::string seq; std::vector<uint8_t> codes; uint64_t inFile = 0;
-    for (;;) {                                                   // inputReader.cpp:26-49: alternate by parity
-        SeqFile& f = (two && (inFile & 1)) ? f2 : f1;
-        if (!f.next(seq)) break;
-        codes.resize(seq.size());
-        for (size_t i = 0; i < seq.size(); i++) codes[i] = g_code[(unsigned char)seq[i]];
-        stage_codes(c, codes.data(), (int)seq.size(), c->pool, c->poolOff, c->poolLen, c->goodReads, c->totalBP, c->smallReads);
-        c->totalReads++; inFile++;
+    const int nt = io_threads(c);
+    const size_t BATCH = 1 << 19;
+    std::string flat; std::vector<uint64_t> boff; uint64_t inFile = 0; bool more = true;
+    std::vector<std::vector<uint64_t>> pools(nt), offs(nt); std::vector<std::vector<uint16_t>> lens(nt);
+    while (more) {
+        flat.clear(); boff.clear(); boff.push_back(0);
+        while (boff.size() <= BATCH) {                             // inputReader.cpp:26-49: alternate by parity
+            SeqFile& f = (two && (inFile & 1)) ? f2 : f1;
+            size_t len = 0;
+            if (!f.next(flat, len)) { more = false; break; }
+            boff.push_back(flat.size()); inFile++;
+        }
+        const int64_t nb = (int64_t)boff.size() - 1; if (nb == 0) break;
+        std::vector<uint64_t> good(nt, 0), bp(nt, 0), small(nt, 0);
+        for (int t = 0; t < nt; t++) { pools[t].clear(); offs[t].clear(); lens[t].clear(); }
+        #pragma omp parallel num_threads(nt)
+        {
+            const int t = omp_get_thread_num(); const int64_t chunk = (nb + nt - 1) / nt, a = t * chunk, b = std::min<int64_t>(nb, a + chunk);
+            std::vector<uint8_t> codes;
+            for (int64_t r = a; r < b; r++) {
+                const size_t L = boff[r + 1] - boff[r]; codes.resize(L);
+                const unsigned char* sq = (const unsigned char*)flat.data() + boff[r];
+                for (size_t i = 0; i < L; i++) codes[i] = g_code[sq[i]];
+                stage_codes(c, codes.data(), (int)L, pools[t], offs[t], lens[t], good[t], bp[t], small[t]);
+            }
+        }
+        for (int t = 0; t < nt; t++) {                              // concatenate in file order (thread t holds a contiguous slice)
+            const uint64_t base = c->pool.size();
+            c->pool.insert(c->pool.end(), pools[t].begin(), pools[t].end());
+            for (uint64_t o : offs[t]) c->poolOff.push_back(base + o);
+            c->poolLen.insert(c->poolLen.end(), lens[t].begin(), lens[t].end());
+            c->goodReads += good[t]; c->totalBP += bp[t]; c->smallReads += small[t];
+        }
+        c->totalReads += (uint64_t)nb;
     }
     return SAGE2OV_OK;
 }
@@ -230,20 +283,43 @@ struct Replay {
         }
         // marks on the final lists (all reads first: they read their neighbours' unreduced lists), then the removals (:681-707)
         const int64_t n = (int64_t)ids.size();
-        #pragma omp parallel if (n > 4096)
+        const int nthr = io_threads(c);
+        #pragma omp parallel num_threads(nthr) if (n > 4096)
         {
             std::vector<uint8_t> mkb(idOf.size(), 0);
             #pragma omp for schedule(dynamic, 1024)
             for (int64_t x = 0; x < n; x++) { const uint32_t d = dense[ids[x]] - 1; if (st[d] == 2 && !adj[d].empty()) mark_edges(ids[x], mkb); }
         }
         uint64_t rem = 0;
-        #pragma omp parallel for schedule(dynamic, 1024) reduction(+ : rem) if (n > 4096)
+        #pragma omp parallel for num_threads(nthr) schedule(dynamic, 1024) reduction(+ : rem) if (n > 4096)
         for (int64_t x = 0; x < n; x++) { const uint32_t d = dense[ids[x]] - 1; if (st[d] == 2) rem += remove_marked(ids[x]); }
         removed += rem;
     }
 };
 
 }  // namespace
+
+static inline char* put_u(char* p, unsigned long long v) {          // decimal, no sign, no padding (what %u / %llu print)
+    char t[24]; int n = 0; do { t[n++] = (char)('0' + v % 10); v /= 10; } while (v); while (n) *p++ = t[--n]; return p;
+}
+// text of items [0, n) produced by `fmt(i, out)` (appends to a std::string), formatted by all threads in contiguous slices and written in order
+template <class F>
+static int write_formatted(sage2ov_ctx* c, FILE* f, uint64_t n, size_t bytes_per_item, F fmt) {
+    const int nt = io_threads(c);
+    const uint64_t BATCH = (uint64_t)nt * 262144;                            // bounded memory: tens of MB per thread
+    std::vector<std::string> out(nt);
+    for (uint64_t b0 = 0; b0 < n; b0 += BATCH) {
+        const uint64_t nb = std::min<uint64_t>(BATCH, n - b0);
+        #pragma omp parallel num_threads(nt)
+        {
+            const int t = omp_get_thread_num(); const uint64_t chunk = (nb + nt - 1) / nt, a = b0 + t * chunk, e = std::min(b0 + nb, a + chunk);
+            out[t].clear(); if (a < e) out[t].reserve((size_t)(e - a) * bytes_per_item);
+            for (uint64_t i = a; i < e; i++) fmt(i, out[t]);
+        }
+        for (int t = 0; t < nt; t++) if (!out[t].empty() && fwrite(out[t].data(), 1, out[t].size(), f) != out[t].size()) return c->fail(SAGE2OV_ERR_IO, "write failed");
+    }
+    return SAGE2OV_OK;
+}
 
 // ============================================================================================ C ABI
 extern "C" {
@@ -304,7 +380,7 @@ int sage2ov_reads_add_list(sage2ov_ctx* c, const char* lp) {                    
 int sage2ov_reads_add_synth(sage2ov_ctx* c, const sage2ov_synth_params* p, const uint8_t* genome, uint64_t first, uint64_t n) {
     if (!c || !p || !genome) return SAGE2OV_ERR_ARG;
     if (c->organized) return c->fail(SAGE2OV_ERR_ARG, "reads already organised");
-    const int nt = c->cfg.host_threads ? (int)c->cfg.host_threads : omp_get_max_threads();
+    const int nt = io_threads(c);
     std::vector<std::vector<uint64_t>> pools(nt), offs(nt); std::vector<std::vector<uint16_t>> lens(nt);
     std::vector<uint64_t> good(nt, 0), bp(nt, 0), small(nt, 0);
     int rcAll = 0;
@@ -345,7 +421,7 @@ static int choose_S(int maxL) { int need = (2 * maxL + 16 + 63) / 64; int S = 4;
 int sage2ov_reads_organize(sage2ov_ctx* c) {                                          // readLoader.cpp:215-260
     if (!c) return SAGE2OV_ERR_ARG;
     if (c->organized) return c->fail(SAGE2OV_ERR_ARG, "reads already organised");
-    if (c->cfg.host_threads) omp_set_num_threads((int)c->cfg.host_threads);
+    omp_set_num_threads(io_threads(c));
     const uint64_t n = c->poolLen.size();
     int maxL = 0; for (uint64_t i = 0; i < n; i++) maxL = std::max<int>(maxL, c->poolLen[i]);
     c->maxL = maxL; c->S = choose_S(std::max(maxL, 1));
@@ -431,14 +507,17 @@ int sage2ov_reads_save(sage2ov_ctx* c, const char* path) {                      
     FILE* f = fopen(path, "w"); if (!f) return c->fail(SAGE2OV_ERR_IO, std::string("cannot open ") + path);
     std::vector<char> io(1 << 22); setvbuf(f, io.data(), _IOFBF, io.size());
     fprintf(f, "%llu\n", (unsigned long long)c->N);
-    std::vector<char> a(c->maxL + 1), b(c->maxL + 1); uint64_t r[18];
-    for (uint64_t i = 1; i <= c->N; i++) {
-        const int L = c->len[i]; const uint64_t* w = &c->words[i * c->S];
-        uint64_t tmp[18]; const int nw = (L + 31) / 32; for (int q = 0; q < nw; q++) tmp[q] = w[q]; if (nw == c->S) tmp[nw - 1] &= ~0xFFFFull;
-        words_to_ascii(tmp, L, a.data()); revcomp_words(tmp, nw, L, r); words_to_ascii(r, L, b.data());
-        fprintf(f, "%u\t%u\t%.*s\t%.*s\n", (unsigned)c->freq[i], (unsigned)L, L, a.data(), L, b.data());
-    }
-    fclose(f); return SAGE2OV_OK;
+    const int S = c->S;
+    int rc = write_formatted(c, f, c->N, (size_t)(2 * c->maxL + 24), [&](uint64_t x, std::string& o) {
+        const uint64_t i = x + 1; const int L = c->len[i]; const uint64_t* w = &c->words[i * S];
+        uint64_t tmp[18], r[18]; const int nw = (L + 31) / 32; for (int q = 0; q < nw; q++) tmp[q] = w[q]; if (nw == S) tmp[nw - 1] &= ~0xFFFFull;
+        revcomp_words(tmp, nw, L, r);
+        char hd[48]; char* p = put_u(hd, c->freq[i]); *p++ = '\t'; p = put_u(p, (unsigned)L); *p++ = '\t';
+        const size_t at = o.size(); o.resize(at + (size_t)(p - hd) + 2 * (size_t)L + 2);
+        char* d = &o[at]; memcpy(d, hd, (size_t)(p - hd)); d += p - hd;
+        words_to_ascii(tmp, L, d); d += L; *d++ = '\t'; words_to_ascii(r, L, d); d += L; *d++ = '\n';
+    });
+    fclose(f); return rc;
 }
 int sage2ov_reads_load(sage2ov_ctx* c, const char* path) {                            // readLoader.cpp:289-307, :38-48
     if (!c || !path) return SAGE2OV_ERR_ARG;
@@ -548,6 +627,7 @@ int sage2ov_overlap_initial(sage2ov_ctx* c) {
 int sage2ov_overlap_reduce(sage2ov_ctx* c) {
     if (!c) return SAGE2OV_ERR_ARG; if (!c->reciprocalDone) return c->fail(SAGE2OV_ERR_ARG, "run the initial pass first");
     auto t0 = std::chrono::steady_clock::now();
+    omp_set_num_threads(io_threads(c));                          // (the parallel sort and the marks of the host replay)
     // Many unresolved reads and no long bucket: the order-independent form runs on the device; the serial
     // replay below stays the path for long-bucket indexes (A.7) and for a handful of reads.  Both are exact.
     {
@@ -636,11 +716,16 @@ int sage2ov_graph_save(sage2ov_ctx* c, const char* path) {                      
     FILE* f = fopen(path, "w"); if (!f) return c->fail(SAGE2OV_ERR_IO, std::string("cannot open ") + path);
     std::vector<char> io(1 << 22); setvbuf(f, io.data(), _IOFBF, io.size());
     fprintf(f, "0\n%llu\n%llu\n", (unsigned long long)c->goodReads, (unsigned long long)(c->goodReads ? c->totalBP / c->goodReads : 0));
-    for (const FinalEdge& e : c->edges) {
-        fprintf(f, "%u\t%u\t%u\t1\t%u\t0\t0\n\n", e.from, e.to, e.type, e.len);
-        fprintf(f, "%u\t%u\t%u\t1\t%u\t0\t0\n\n", e.to, e.from, (unsigned)flip_type_host((int)e.type), e.len_twin);
-    }
-    fclose(f); return SAGE2OV_OK;
+    auto rec = [](char* p, unsigned a, unsigned b, unsigned t, unsigned len) {           // "%u\t%u\t%u\t1\t%u\t0\t0\n\n"
+        p = put_u(p, a); *p++ = '\t'; p = put_u(p, b); *p++ = '\t'; p = put_u(p, t); memcpy(p, "\t1\t", 3); p += 3; p = put_u(p, len); memcpy(p, "\t0\t0\n\n", 6); return p + 6;
+    };
+    rc = write_formatted(c, f, c->edges.size(), 96, [&](uint64_t x, std::string& o) {
+        const FinalEdge& e = c->edges[x]; char buf[128];
+        char* p = rec(buf, e.from, e.to, e.type, e.len);
+        p = rec(p, e.to, e.from, (unsigned)flip_type_host((int)e.type), e.len_twin);
+        o.append(buf, (size_t)(p - buf));
+    });
+    fclose(f); return rc;
 }
 
 int sage2ov_run_steps23(sage2ov_ctx* c) {
