@@ -275,6 +275,10 @@ def main():
             "reads_per_s": st.unique_reads / (elapsed / args.steps),
             "roofline": {"bound": "hbm", "kernel": "k_probe_fast", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                         # memory-side bytes per launch (PMC, profiles/probe_traffic.json) over the live kernel time: what the kernel really pulls
+                         "traffic_achieved": (traffic * share / (kern_ms * 1e-3) / 1e9) if (traffic and kern_ms > 0) else None,
+                         "traffic_frac": (traffic * share / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and kern_ms > 0) else None,
+                         "limiter": "128-byte line requests (x2.75 of the algorithmic bytes) and instruction issue, both near 2/3 of their ceilings (DESIGN.md 5.2)",
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": a_probe * share,
                          "whole_path_achieved": a_total / (elapsed / args.steps) / 1e9, "whole_path_frac": a_total / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
         }
