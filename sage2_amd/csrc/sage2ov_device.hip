@@ -175,8 +175,24 @@ int dev_organize_reads(Device* d, const uint64_t* pool, uint64_t pool_words, con
             hipLaunchKernelGGL(k_rs_scatter, dim3(nb), dim3(64), 0, d->stream, ka, va, (u64)n, 8 * pass, hscan, nb, kb, vb);
             std::swap(ka, kb); std::swap(va, vb);
         }
-        hipLaunchKernelGGL(k_org_ties, dim3(grid_for(n, 256)), dim3(256), 0, d->stream, ka, va, (u64)n, img, S);
         WS(flag, u32, WS_ORG_FLAG, n + 2); WS(uid, u32, WS_ORG_UID, n + 2);
+        u32 longrun = 0;
+        HIPCHK(hipMemsetAsync(flag, 0, sizeof(u32), d->stream));
+        hipLaunchKernelGGL(k_org_longrun, dim3(grid_for(n, 256)), dim3(256), 0, d->stream, ka, (u64)n, flag);
+        HIPCHK(hipMemcpyAsync(&longrun, flag, sizeof longrun, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
+        if (longrun || getenv("SAGE2OV_TEST_FULL_SORT")) {
+            // many reads share their first 32 bases: order on every word instead (stable LSD radix, last word first; the pairs arrive
+            // sorted by the first word, which the last eight passes simply reproduce)
+            for (int c = S - 1; c >= 0; c--) {
+                hipLaunchKernelGGL(k_org_wordkeys, dim3(grid_for(n, 256)), dim3(256), 0, d->stream, img, S, c, va, (u64)n, ka);
+                for (int pass = 0; pass < 8; pass++) {
+                    hipLaunchKernelGGL(k_rs_hist, dim3(nb), dim3(64), 0, d->stream, ka, (u64)n, 8 * pass, hist, nb);
+                    u64 tot = 0; int rc = scan_u32(d, hist, (u64)256 * nb, hscan, &tot, err); if (rc) return rc;
+                    hipLaunchKernelGGL(k_rs_scatter, dim3(nb), dim3(64), 0, d->stream, ka, va, (u64)n, 8 * pass, hscan, nb, kb, vb);
+                    std::swap(ka, kb); std::swap(va, vb);
+                }
+            }
+        } else hipLaunchKernelGGL(k_org_ties, dim3(grid_for(n, 256)), dim3(256), 0, d->stream, ka, va, (u64)n, img, S);
         hipLaunchKernelGGL(k_org_heads, dim3(grid_for(n, 256)), dim3(256), 0, d->stream, ka, va, (u64)n, img, S, flag);
         { int rc = scan_u32(d, flag, n, uid, &N, err); if (rc) return rc; }
         if (N >= (1ull << 30)) { err = "more than 2^30-1 unique reads per context is not supported yet"; return SAGE2OV_ERR_LIMIT; }

@@ -534,3 +534,39 @@ def test_read_length_layout_boundaries_match_oracle(L):
     gp, gl_, gf = g.reads_export(); op, ol_, of = o.export_reads()
     assert np.array_equal(gl_, ol_) and np.array_equal(gf, of)
     g.close(); o.close()
+
+
+def test_device_organizer_long_runs_of_equal_prefixes(monkeypatch):
+    """Thousands of distinct reads that share their first 40 bases (adapter dimers, amplicons), plus heavy exact duplication: the per-run
+    insertion sort of the device organiser would be quadratic, so it must switch to the all-words radix sort -- same ids as the host."""
+    rng = np.random.default_rng(11)
+    prefix = "".join(rng.choice(list("ACGT"), size=40))
+    reads = [prefix + "".join(rng.choice(list("ACGT"), size=60)) for _ in range(6000)]
+    reads += [reads[0]] * 3000 + ["".join(rng.choice(list("ACGT"), size=100)) for _ in range(8000)]
+    bases = np.frombuffer("".join(reads).encode(), dtype=np.uint8).copy()
+    off = np.arange(0, (len(reads) + 1) * 100, 100, dtype=np.uint64)
+    out = {}
+    for mode in ("device", "host"):
+        if mode == "host":
+            monkeypatch.setenv("SAGE2OV_HOST_ORGANIZE", "1")
+        else:
+            monkeypatch.delenv("SAGE2OV_HOST_ORGANIZE", raising=False)
+        g = s2.Context(21, device=0); g.reads_add_ascii(bases, off); g.reads_organize()
+        out[mode] = (g.reads_export(), g.reads_stats().unique_reads); g.close()
+    (dp, dl, df), dn = out["device"]; (hp, hl, hf), hn = out["host"]
+    assert dn == hn and np.array_equal(dl, hl) and np.array_equal(df, hf) and np.array_equal(dp, hp)
+    assert int(df.max()) >= 3001
+
+
+def test_device_organizer_full_sort_path_equals_default(monkeypatch):
+    """the all-words radix sort (normally only taken for long runs) on ordinary mixed-length data"""
+    pd = dict(seed=22, genome_len=40000, n_reads=30000, read_len=200, read_len_min=60, err_ppm=2000)
+    bases, off = fx.make_reads(pd)
+    out = {}
+    for mode in ("default", "full"):
+        if mode == "full":
+            monkeypatch.setenv("SAGE2OV_TEST_FULL_SORT", "1")
+        g = s2.Context(21, device=0); g.reads_add_ascii(bases, off); g.reads_organize()
+        out[mode] = g.reads_export(); g.close()
+    for a, b in zip(out["default"], out["full"]):
+        assert np.array_equal(a, b)
