@@ -46,3 +46,41 @@ extern "C" int sage2ref_run_steps123(const char* fasta, int k, int threads, cons
     logStream.close();
     return 0;
 }
+
+// Step 4 of the reference (main.cpp:139-172) on files: load <in_prefix>.reads + <in_prefix>.graph3 with the reference's own loaders,
+// run its simplification loop exactly as main.cpp does, and dump the in-memory graph with the reference's own writer.  The reference
+// itself never writes the post-step-4 graph (its step 5 would read "<prefix>.graph4", main.cpp:196); this is how the fixtures
+// under tests/golden/*.graph4.gz were made.  c[0..3]: unique reads, loop iterations, nodes contracted, edges/reads removed.
+extern "C" int sage2ref_run_step4(const char* in_prefix, int k, int threads, const char* out_graph4, double* t /* [2]: load, simplify */,
+                                  unsigned long long* c /* [4] */) {
+    if (threads > 0) omp_set_num_threads(threads);
+    if (logStream.is_open()) logStream.close();
+    logStream.open((std::string(out_graph4) + ".log").c_str());
+    genomeSize = 0; averageReadLength = 0;
+    double t0 = now_s();
+    ReadLoader* loader = new ReadLoader((uint16_t)k);                              // main.cpp:143
+    loader->loadReadsFromFile(std::string(in_prefix) + ".reads");                  // main.cpp:144
+    OverlapGraph* graph = new OverlapGraph(loader);                                // main.cpp:146
+    graph->loadOverlapGraphFromFile(std::string(in_prefix) + ".graph3");           // main.cpp:147
+    double t1 = now_s();
+    int threshold = 0, closeValue = 10;                                            // main.cpp:150
+    unsigned long long contracted = 0, removed = 0, iters = 0;
+    contracted += contractCompositePaths(graph, loader);                           // main.cpp:151-154
+    removed += removeDeadEnds(graph, loader, threshold);
+    removed += removeBubbles(graph, loader, closeValue);
+    contracted += contractCompositePaths(graph, loader);
+    for (;;) {                                                                     // main.cpp:158-172
+        uint64_t a = removeDeadEnds(graph, loader, threshold), b = removeBubbles(graph, loader, closeValue), cc = contractCompositePaths(graph, loader);
+        removed += a + b; contracted += cc; iters++;
+        if (a + b + cc == 0) break;
+        if (closeValue < 50) closeValue += 10;
+        if (threshold < 3) threshold++;
+    }
+    double t2 = now_s();
+    graph->saveOverlapGraphInFile(out_graph4);
+    t[0] = t1 - t0; t[1] = t2 - t1;
+    c[0] = loader->numberOfUniqueReads; c[1] = iters; c[2] = contracted; c[3] = removed;
+    delete graph; delete loader;
+    logStream.close();
+    return 0;
+}
