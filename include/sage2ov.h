@@ -145,6 +145,27 @@ typedef struct sage2ov_edge {      /* one record pair of P.graph3 (overlapGraph.
 int sage2ov_edges_count(const sage2ov_ctx* ctx, uint64_t* n);
 int sage2ov_edges_export(sage2ov_ctx* ctx, sage2ov_edge* out, uint64_t cap);
 int sage2ov_graph_save(sage2ov_ctx* ctx, const char* path);     /* saveOverlapGraphInFile (overlapGraph.cpp:338) -> P.graph3 */
+/* loadOverlapGraphFromFile's role for a graph of simple edges (overlapGraph.cpp:371): take this edge list (the layout edges_export
+ * writes; pairs are pushed in the order given) instead of computing it -- the entry for step 4 on an existing graph. */
+int sage2ov_edges_import(sage2ov_ctx* ctx, const sage2ov_edge* edges, uint64_t n);
+int sage2ov_graph_load(sage2ov_ctx* ctx, const char* path);     /* loadOverlapGraphFromFile (overlapGraph.cpp:371) <- P.graph3 (simple edges) */
+
+/* ---- step 4: simplification of the overlap graph on the device, main.cpp:139-172 over overlapGraph/simplification.cpp:
+ * contractCompositePaths (:14), removeDeadEnds (:58), removeBubbles (:118) in the reference's loop, with its growing thresholds.
+ * Needs sage2ov_overlap_convert.  The result is the graph the reference holds in memory after its step 4; sage2ov_graph4_save writes
+ * it with saveOverlapGraphInFile's format (overlapGraph.cpp:338-369, :12-20) as `P.graph4`, the file the reference's step 5 reads
+ * (main.cpp:196) but none of its steps writes. */
+typedef struct sage2ov_simplify_stats {
+    uint64_t nodes_contracted;     /* sum of contractCompositePaths' "Nodes removed" */
+    uint64_t removed;              /* sum of removeDeadEnds' and removeBubbles' return values */
+    uint64_t loop_iterations;      /* passes of the while(1) loop, main.cpp:158 */
+    uint64_t edges;                /* surviving edge pairs */
+    uint64_t reads_on_edges;       /* entries of the surviving forward read lists */
+    double   device_ms;
+} sage2ov_simplify_stats;
+int sage2ov_graph_simplify(sage2ov_ctx* ctx);
+int sage2ov_simplify_stats_get(const sage2ov_ctx* ctx, sage2ov_simplify_stats* out);
+int sage2ov_graph4_save(sage2ov_ctx* ctx, const char* path);
 
 /* diagnostic: table census {occupied, inline, claimed-but-unfilled, zero-tag, entries in short CSR buckets} */
 int sage2ov_debug_table(sage2ov_ctx* ctx, uint64_t* out5);

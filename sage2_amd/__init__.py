@@ -40,6 +40,11 @@ class OverlapStats(C.Structure):
                 ("edges", C.c_uint64), ("unresolved_hits", C.c_uint64)]
 
 
+class SimplifyStats(C.Structure):
+    _fields_ = [("nodes_contracted", C.c_uint64), ("removed", C.c_uint64), ("loop_iterations", C.c_uint64), ("edges", C.c_uint64),
+                ("reads_on_edges", C.c_uint64), ("device_ms", C.c_double)]
+
+
 class Timings(C.Structure):
     _fields_ = [("index_ms", C.c_double), ("probe_ms", C.c_double), ("reciprocal_ms", C.c_double), ("reduce_ms", C.c_double),
                 ("convert_ms", C.c_double), ("total_ms", C.c_double), ("probe_kernel_ms", C.c_double), ("probe_kernel_launches", C.c_uint64), ("sequential_reads", C.c_uint64),
@@ -250,8 +255,27 @@ class Context:
             self._chk(lib().sage2ov_edges_export(self._h, C.c_void_p(out.ctypes.data), C.c_uint64(n.value)))
         return out
 
+    def edges_import(self, edges: np.ndarray):
+        edges = np.ascontiguousarray(edges, dtype=EDGE_DTYPE)
+        self._chk(lib().sage2ov_edges_import(self._h, C.c_void_p(edges.ctypes.data), C.c_uint64(len(edges))))
+
+    def graph_load(self, path):
+        self._chk(lib().sage2ov_graph_load(self._h, path.encode()))
+
     def graph_save(self, path):
         self._chk(lib().sage2ov_graph_save(self._h, path.encode()))
+
+    # ---- step 4
+    def graph_simplify(self):
+        self._chk(lib().sage2ov_graph_simplify(self._h))
+
+    def simplify_stats(self) -> SimplifyStats:
+        s = SimplifyStats()
+        self._chk(lib().sage2ov_simplify_stats_get(self._h, C.byref(s)))
+        return s
+
+    def graph4_save(self, path):
+        self._chk(lib().sage2ov_graph4_save(self._h, path.encode()))
 
     def timings(self) -> Timings:
         t = Timings()

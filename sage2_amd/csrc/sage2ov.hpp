@@ -68,10 +68,17 @@ public:
 // OverlapGraph, steps-1-3 part (overlapGraph.h:54-67: convertGraph, saveOverlapGraphInFile)
 class OverlapGraph {
 public:
-    OverlapGraph(EconomyGraph* economy1, ReadLoader*) : economyObj(economy1) {}
-    void convertGraph() { economyObj->ctx().check(sage2ov_overlap_convert(economyObj->ctx().get())); }
-    void saveOverlapGraphInFile(const std::string& path) { economyObj->ctx().check(sage2ov_graph_save(economyObj->ctx().get(), path.c_str())); }
+    OverlapGraph(EconomyGraph* economy1, ReadLoader* loader1) : economyObj(economy1), ctx_(&loader1->context()) {}
+    explicit OverlapGraph(ReadLoader* loader1) : economyObj(nullptr), ctx_(&loader1->context()) {}          // overlapGraph.cpp:47 (graph from a file)
+    void convertGraph() { ctx_->check(sage2ov_overlap_convert(ctx_->get())); }
+    void saveOverlapGraphInFile(const std::string& path) { ctx_->check(sage2ov_graph_save(ctx_->get(), path.c_str())); }
+    void loadOverlapGraphFromFile(const std::string& path) { ctx_->check(sage2ov_graph_load(ctx_->get(), path.c_str())); }
+    // step 4: the loop of main.cpp:150-172 over contractCompositePaths / removeDeadEnds / removeBubbles (simplification.cpp), on the device
+    sage2ov_simplify_stats simplify() { ctx_->check(sage2ov_graph_simplify(ctx_->get())); sage2ov_simplify_stats s{}; ctx_->check(sage2ov_simplify_stats_get(ctx_->get(), &s)); return s; }
+    void saveSimplifiedGraphInFile(const std::string& path) { ctx_->check(sage2ov_graph4_save(ctx_->get(), path.c_str())); }   // what step 5 loads (main.cpp:196)
     EconomyGraph* economyObj;
+private:
+    Context* ctx_;
 };
 
 }  // namespace sage2ov

@@ -21,7 +21,7 @@ static void printUsage() {
 static void printListOfArgs() {
     cout << "\t-f|--fileInput <string>\tinterleaved FASTA/FASTQ(.gz)\n\t-l|--listInput <string>\tlist file (f1=/f2=/f=)\n"
             "\t-k|--minOverlap <int>\tminimum overlap (required)\n\t-o|--outputDir <string>\n\t-p|--prefix <string>\t[untitled]\n"
-            "\t-i|--inputPrefix <string>\t[prefix]\n\t-m|--minStep <int>\t[1]\n\t-M|--maxStep <int>\t[3] (steps 4-7: run SAGE2 -m 4 on the files written here)\n"
+            "\t-i|--inputPrefix <string>\t[prefix]\n\t-m|--minStep <int>\t[1]\n\t-M|--maxStep <int>\t[3] (4 = simplified graph P.graph4; steps 5-7: run SAGE2 -m 5 on the files written here)\n"
             "\t-s|--saveAll\n\t-d|--debug\n\t-g|--gpu <int>\tHIP device ordinal [0]\n\t-h|--help\n\n";
 }
 static string trimBack(string s, const string& pat) { size_t e = s.find_last_not_of(pat); return e == string::npos ? "" : s.substr(0, e + 1); }
@@ -60,17 +60,17 @@ int main(int argc, char* argv[]) {
     if (maxStep < minStep) { cout << "[ERROR] maxStep should not be smaller than minStep!\n\n"; allSet = false; }
     if (inputPrefix == "") inputPrefix = prefixName;
     if (!allSet) { cout << "\n"; printUsage(); cout << "(For more information run sage2ov -h)\n\n"; exit(0); }
-    if (minStep > 3) { cout << "[ERROR] sage2ov implements steps 1-3; continue with: SAGE2 -m " << minStep << " -i " << inputPrefix << " ...\n"; exit(0); }
+    if (minStep > 4) { cout << "[ERROR] sage2ov implements steps 1-4; continue with: SAGE2 -m " << minStep << " -i " << inputPrefix << " ...\n"; exit(0); }
     (void)debugging;
     if (outputDir != "") { string cmd = "mkdir -p " + outputDir; if (system(cmd.c_str())) {} }     // utils.cpp:45
     ofstream logStream((outputDir + prefixName + ".log").c_str());
     logStream << "***********************************************************************************************************\n"
-              << "\tEXECUTING PROGRAM: sage2ov (MI355X-native SAGE2 steps 1-3), " << sage2ov_version() << "\n"
+              << "\tEXECUTING PROGRAM: sage2ov (MI355X-native SAGE2 steps 1-4), " << sage2ov_version() << "\n"
               << (listInput != "" ? "\t  INPUT LIST PATH: " + listInput : "\t  INPUT FILE PATH: " + fileInput) << "\n"
               << "\t OUTPUT DIRECTORY: " << outputDir << "\n\t    OUTPUT PREFIX: " << prefixName << "\n\t  MINIMUM OVERLAP: " << minOverlap << "\n"
               << "\t       START STEP: " << minStep << "\n\t         END STEP: " << maxStep << "\n\t   SAVE ALL FILES: " << (saveAll ? "TRUE" : "FALSE") << "\n"
               << "***********************************************************************************************************\n\n";
-    const int lastStep = maxStep > 3 ? 3 : maxStep;
+    const int lastStep = maxStep > 4 ? 4 : maxStep;
     try {
         Context ctx((uint16_t)minOverlap, lastStep == 1 ? SAGE2OV_DEVICE_NONE : gpu);
         ReadLoader loaderObj(ctx);
@@ -87,7 +87,19 @@ int main(int argc, char* argv[]) {
             loaderObj.loadReadsFromFile(outputDir + inputPrefix + ".reads");                 // main.cpp:70-74 / :101-104
             logStream << "\tNumber of unique reads: " << loaderObj.numberOfUniqueReads << " (loaded)\n";
         }
-        if (lastStep >= 2) {
+        auto step4 = [&](OverlapGraph& graphObj) {                                            // main.cpp:134-181
+            double t4 = now();
+            auto ss = graphObj.simplify();
+            logStream << "STEP 4: simplify overlap graph\n\t   Nodes removed: " << ss.nodes_contracted << "\n\tDead ends and bubbles removed: " << ss.removed
+                      << "\n\tLoop iterations: " << ss.loop_iterations << "\n\tEdges left: " << ss.edges << " carrying " << ss.reads_on_edges << " reads\n\tStep 4 in " << now() - t4
+                      << " sec (device " << ss.device_ms / 1000.0 << ").\n";
+            graphObj.saveSimplifiedGraphInFile(outputDir + prefixName + ".graph4");          // the file step 5 loads (main.cpp:196)
+        };
+        if (minStep == 4) {                                                                   // main.cpp:141-148
+            OverlapGraph graphObj(&loaderObj);
+            graphObj.loadOverlapGraphFromFile(outputDir + inputPrefix + ".graph3");
+            step4(graphObj);
+        } else if (lastStep >= 2) {
             HashTable hashObj(&loaderObj);
             t0 = now(); hashObj.hashPrefixesAndSuffix();                                      // main.cpp:76-77 (always rebuilt: P.hashTable is not read)
             auto is = hashObj.stats();
@@ -111,12 +123,13 @@ int main(int argc, char* argv[]) {
                 graphObj.convertGraph();
                 logStream << "     Edges in the graph: " << economyObj.stats().edges << "\n\tStep 3 in " << now() - t0 << " sec.\n";
                 if (minStep == 1 && !saveAll) loaderObj.saveReadsInFile(outputDir + prefixName + ".reads");
-                graphObj.saveOverlapGraphInFile(outputDir + prefixName + ".graph3");
+                if (lastStep == 3 || saveAll) graphObj.saveOverlapGraphInFile(outputDir + prefixName + ".graph3");      // main.cpp:120-131
+                if (lastStep >= 4) step4(graphObj);
             }
         }
-        if (maxStep > 3) {
-            cout << "sage2ov: steps 1-3 done; continue with the reference: SAGE2 " << (listInput != "" ? "-l " + listInput : "-f " + fileInput) << " -k " << minOverlap
-                 << " -o " << (outputDir == "" ? "." : outputDir) << " -p " << prefixName << " -i " << prefixName << " -m 4 -M " << maxStep << "\n";
+        if (maxStep > 4) {
+            cout << "sage2ov: steps 1-4 done; continue with the reference: SAGE2 " << (listInput != "" ? "-l " + listInput : "-f " + fileInput) << " -k " << minOverlap
+                 << " -o " << (outputDir == "" ? "." : outputDir) << " -p " << prefixName << " -i " << prefixName << " -m 5 -M " << maxStep << "\n";
         }
     } catch (const Error& e) {
         logStream << "sage2ov error " << e.code << " : " << e.what() << "!\n";               // utils.cpp:36-40 printError

@@ -82,6 +82,7 @@ static void* ws_get(Device* d, int id, size_t bytes) {
 #include "kernels_reciprocal.inc"
 #include "kernels_reduce.inc"
 #include "kernels_convert.inc"
+#include "kernels_simplify.inc"
 
 // =============================================================================================
 // host-side launchers
@@ -738,6 +739,13 @@ int dev_download_edges(Device* d, std::vector<FinalEdge>& out, std::string& err)
     if (d->n_final) HIPCHK(hipMemcpy(out.data(), d->final_edges, d->n_final * sizeof(FinalEdge), hipMemcpyDeviceToHost));
     return 0;
 }
+int dev_upload_edges(Device* d, const std::vector<FinalEdge>& in, std::string& err) {
+    HIPCHK(hipSetDevice(d->ordinal));
+    WS(fe, FinalEdge, WS_FINAL, std::max<size_t>(1, in.size()));
+    if (!in.empty()) HIPCHK(hipMemcpy(fe, in.data(), in.size() * sizeof(FinalEdge), hipMemcpyHostToDevice));
+    d->final_edges = fe; d->n_final = in.size();
+    return 0;
+}
 int dev_convert(Device* d, uint64_t* n_final, std::string& err) {
     HIPCHK(hipSetDevice(d->ordinal));
     const u64 N = d->N, n = d->n_cand;
@@ -767,6 +775,183 @@ int dev_convert(Device* d, uint64_t* n_final, std::string& err) {
     HIPCHK(hipStreamSynchronize(d->stream));
     float ms = 0; hipEventElapsedTime(&ms, d->ev[0], d->ev[1]); d->tm.convert_ms += ms;
     *n_final = d->n_final;
+    return 0;
+}
+
+// =============================================================================================
+// step 4: simplification of the overlap graph in HBM (main.cpp:139-172).  Input: the final edges of step 3 (device resident, .graph3 order).
+// =============================================================================================
+namespace {
+struct S4Mem {                                   // freed on every exit path
+    std::vector<void*> ptrs;
+    template <class T> T* get(size_t n, std::string& err) { void* p = nullptr; if (hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) { err = "step 4: device allocation failed"; return nullptr; } ptrs.push_back(p); return (T*)p; }
+    void drop(void* p) { for (auto& q : ptrs) if (q == p) { hipFree(q); q = nullptr; } }
+    ~S4Mem() { for (void* p : ptrs) if (p) hipFree(p); }
+};
+}
+#define S4GET(var, type, n) type* var = mem.get<type>((n), err); if (!var) return SAGE2OV_ERR_NOMEM;
+
+int dev_simplify(Device* d, SimplifiedGraph& out, std::string& err) {
+    HIPCHK(hipSetDevice(d->ordinal));
+    const u64 N64 = d->N, np = d->n_final;
+    if (2 * np + 2 * (N64 + 1) >= (1ull << 32)) { err = "step 4: too many edges"; return SAGE2OV_ERR_LIMIT; }
+    const u32 N = (u32)N64, capH = (u32)(2 * np + 2 * (N64 + 1));
+    S4Mem mem; S4Graph g;
+    { S4GET(a, u32, capH) g.from = a; } { S4GET(a, u32, capH) g.to = a; } { S4GET(a, u32, capH) g.len = a; } { S4GET(a, u32, capH) g.cnt = a; } { S4GET(a, u32, capH) g.off = a; }
+    { S4GET(a, uint8_t, capH) g.type = a; } { S4GET(a, uint8_t, capH) g.alive = a; }
+    { S4GET(a, u32, N + 2) g.deg = a; } { S4GET(a, u32, N + 2) g.adjOff = a; } { S4GET(a, u32, capH) g.adj = a; }
+    u64 listCap = std::max<u64>(4 * (N64 + 1), 1 << 16), listUsed = 0;
+    { S4GET(a, u64, listCap) g.lists = a; }
+    S4GET(cursor, u32, N + 2) S4GET(cont, uint8_t, N + 2) S4GET(forced, uint8_t, N + 2) S4GET(role, uint8_t, N + 2) S4GET(h0, u32, N + 2) S4GET(h1, u32, N + 2)
+    S4GET(stA, S4State, 2 * (size_t)(N + 1)) S4GET(stB, S4State, 2 * (size_t)(N + 1))
+    S4GET(isNew, u32, N + 2) S4GET(newCnt, u32, N + 2) S4GET(rank, u32, N + 2) S4GET(cntScan, u32, N + 2)
+    S4GET(chain, S4Chain, capH) S4GET(jobs, S4Job, 4 * (size_t)(N + 1)) S4GET(jobLen, u32, 4 * (size_t)(N + 1)) S4GET(jobStart, u32, 4 * (size_t)(N + 1))
+    S4GET(decA, uint8_t, N + 2) S4GET(decB, uint8_t, N + 2) S4GET(othA, u32, N + 2) S4GET(othB, u32, N + 2) S4GET(remA, u32, capH) S4GET(remB, u32, capH)
+    S4GET(dctr, u32, 8)
+    u32 tabBits = 10; while ((1ull << tabBits) < 2ull * (N64 + 2)) tabBits++;
+    const u32 tabMask = (u32)((1ull << tabBits) - 1);
+    S4GET(tab, S4Pair, (size_t)1 << tabBits)
+    u32 nh = (u32)(2 * np);
+    hipStream_t st = d->stream;
+    HIPCHK(hipEventRecord(d->ev[0], st));
+    if (np) hipLaunchKernelGGL(k_s4_init, dim3(grid_for(np, 256)), dim3(256), 0, st, d->final_edges, (u64)np, g);
+    auto rd = [&](u32* v, int n) -> int { return hipMemcpyAsync(v, dctr, n * sizeof(u32), hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess ? 0 : -1; };
+    auto adjacency = [&]() -> int {
+        HIPCHK(hipMemsetAsync(g.deg, 0, (N + 2) * sizeof(u32), st)); HIPCHK(hipMemsetAsync(cursor, 0, (N + 2) * sizeof(u32), st));
+        if (nh) hipLaunchKernelGGL(k_s4_degree, dim3(grid_for(nh, 256)), dim3(256), 0, st, g, nh);
+        u64 tot = 0; int rc = scan_u32(d, g.deg, (u64)N + 1, g.adjOff, &tot, err); if (rc) return rc;
+        if (nh) hipLaunchKernelGGL(k_s4_fill, dim3(grid_for(nh, 256)), dim3(256), 0, st, g, nh, cursor);
+        hipLaunchKernelGGL(k_s4_sortadj, dim3(grid_for((u64)N + 1, 256)), dim3(256), 0, st, g, N);
+        return 0;
+    };
+    const dim3 gN(grid_for((u64)N + 1, 256)), gS(grid_for(2 * ((u64)N + 1), 256)), b256(256);
+    int jumpRounds = 1; while ((1ull << jumpRounds) < 2ull * (N64 + 2)) jumpRounds++;
+    // ---- contractCompositePaths (simplification.cpp:14-53)
+    auto contract = [&](u64* merged) -> int {
+        int rc = adjacency(); if (rc) return rc;
+        HIPCHK(hipMemsetAsync(forced, 0, N + 2, st));
+        const S4State* fin = nullptr;
+        for (int round = 0;; round++) {
+            if (round > 64) { err = "step 4: chain promotion does not settle"; return SAGE2OV_ERR_INTERNAL; }
+            hipLaunchKernelGGL(k_s4_contractible, gN, b256, 0, st, g, N, forced, cont, h0, h1);
+            hipLaunchKernelGGL(k_s4_state_init, gS, b256, 0, st, g, N, cont, h0, h1, stA);
+            S4State* a = stA; S4State* b = stB;
+            for (int r = 0; r < jumpRounds; r++) {                                   // stops as soon as every state has reached its chain end (cycles never do)
+                HIPCHK(hipMemsetAsync(dctr, 0, sizeof(u32), st));
+                hipLaunchKernelGGL(k_s4_jump, gS, b256, 0, st, N, cont, a, b, dctr); std::swap(a, b);
+                u32 open = 0; if (rd(&open, 1)) { err = "step 4: counter read failed"; return SAGE2OV_ERR_DEVICE; }
+                if (!open) break;
+            }
+            fin = a;
+            HIPCHK(hipMemsetAsync(tab, 0xFF, sizeof(S4Pair) << tabBits, st)); HIPCHK(hipMemsetAsync(dctr, 0, 8 * sizeof(u32), st));
+            hipLaunchKernelGGL(k_s4_chain, gN, b256, 0, st, g, N, cont, fin, role, tab, tabMask, dctr);
+            hipLaunchKernelGGL(k_s4_parallel, gN, b256, 0, st, g, N, fin, role, tab, tabMask, dctr);
+            u32 promoted = 0; if (rd(&promoted, 1)) { err = "step 4: counter read failed"; return SAGE2OV_ERR_DEVICE; }
+            if (!promoted) break;
+            hipLaunchKernelGGL(k_s4_promote, gN, b256, 0, st, N, role, forced);
+        }
+        hipLaunchKernelGGL(k_s4_creator_counts, gN, b256, 0, st, N, role, fin, isNew, newCnt);
+        u64 nNew = 0, nList = 0;
+        rc = scan_u32(d, isNew, (u64)N + 1, rank, &nNew, err); if (rc) return rc;
+        rc = scan_u32(d, newCnt, (u64)N + 1, cntScan, &nList, err); if (rc) return rc;
+        if (!nNew) { *merged = 0; return 0; }
+        if ((u64)nh + 2 * nNew > capH) { err = "step 4: half-edge pool exhausted"; return SAGE2OV_ERR_INTERNAL; }
+        if (listUsed + 2 * nList >= (1ull << 32)) { err = "step 4: read lists exceed 2^32 entries"; return SAGE2OV_ERR_LIMIT; }
+        if (listUsed + 2 * nList > listCap) {                                       // grow the list pool (old segments stay where they are)
+            const u64 want = std::max<u64>(2 * listCap, listUsed + 2 * nList);
+            u64* nl = mem.get<u64>(want, err); if (!nl) return SAGE2OV_ERR_NOMEM;
+            if (listUsed) HIPCHK(hipMemcpyAsync(nl, g.lists, listUsed * sizeof(u64), hipMemcpyDeviceToDevice, st));
+            HIPCHK(hipStreamSynchronize(st)); mem.drop(g.lists); g.lists = nl; listCap = want;
+        }
+        HIPCHK(hipMemsetAsync(dctr, 0, 8 * sizeof(u32), st));
+        hipLaunchKernelGGL(k_s4_emit, gN, b256, 0, st, g, N, role, fin, h0, h1, rank, cntScan, nh, (u32)listUsed, chain);
+        hipLaunchKernelGGL(k_s4_entries, gN, b256, 0, st, g, N, role, fin, h0, h1, chain, jobs, dctr);
+        u32 nj = 0; if (rd(&nj, 1)) { err = "step 4: counter read failed"; return SAGE2OV_ERR_DEVICE; }
+        if (nj) {
+            hipLaunchKernelGGL(k_s4_job_len, dim3(grid_for(nj, 256)), b256, 0, st, jobs, nj, jobLen);
+            u64 total = 0; rc = scan_u32(d, jobLen, nj, jobStart, &total, err); if (rc) return rc;
+            if (total) hipLaunchKernelGGL(k_s4_copy, dim3(grid_for(total, 256)), b256, 0, st, jobs, nj, jobStart, (u64)total, g.lists);
+        }
+        nh += (u32)(2 * nNew); listUsed += 2 * nList;
+        *merged = nNew;                                                            // (non-zero: the caller counts the merged nodes)
+        return 0;
+    };
+    // merged nodes of a sweep = nodes with role 1 or 2 (every one of them is one successful mergeEdges)
+    auto count_roles = [&](u64* n) -> int {
+        HIPCHK(hipMemsetAsync(dctr, 0, 8 * sizeof(u32), st));
+        hipLaunchKernelGGL(k_s4_count_nz, gN, b256, 0, st, N, role, dctr);
+        u32 v = 0; if (rd(&v, 1)) { err = "step 4: counter read failed"; return SAGE2OV_ERR_DEVICE; }
+        *n = v; return 0;
+    };
+    auto contract_counted = [&](u64* merged) -> int { u64 m = 0; int rc = contract(&m); if (rc) return rc; if (!m) { *merged = 0; return 0; } return count_roles(merged); };
+    // ---- removeDeadEnds (simplification.cpp:58-113)
+    auto dead_ends = [&](int threshold, u64* removed) -> int {
+        int rc = adjacency(); if (rc) return rc;
+        HIPCHK(hipMemsetAsync(decA, 0, N + 2, st)); HIPCHK(hipMemsetAsync(decB, 0, N + 2, st));
+        uint8_t* in = decA; uint8_t* o = decB;
+        for (int it = 0;; it++) {
+            if (it > 100000) { err = "step 4: dead-end sweep does not settle"; return SAGE2OV_ERR_INTERNAL; }
+            HIPCHK(hipMemsetAsync(dctr, 0, 8 * sizeof(u32), st));
+            hipLaunchKernelGGL(k_s4_dead, gN, b256, 0, st, g, N, threshold, in, o, dctr);
+            u32 ch = 0; if (rd(&ch, 1)) { err = "step 4: counter read failed"; return SAGE2OV_ERR_DEVICE; }
+            std::swap(in, o);
+            if (!ch) break;
+        }
+        HIPCHK(hipMemsetAsync(dctr, 0, 8 * sizeof(u32), st));
+        hipLaunchKernelGGL(k_s4_count, gN, b256, 0, st, N, in, dctr);
+        if (nh) hipLaunchKernelGGL(k_s4_dead_apply, dim3(grid_for(nh, 256)), b256, 0, st, g, nh, in);
+        u32 v = 0; if (rd(&v, 1)) { err = "step 4: counter read failed"; return SAGE2OV_ERR_DEVICE; }
+        *removed = v; return 0;
+    };
+    // ---- removeBubbles (simplification.cpp:118-194)
+    auto bubbles = [&](long long closeLength, u64* removed) -> int {
+        int rc = adjacency(); if (rc) return rc;
+        HIPCHK(hipMemsetAsync(decA, 0, N + 2, st)); HIPCHK(hipMemsetAsync(othA, 0, (N + 2) * sizeof(u32), st)); HIPCHK(hipMemsetAsync(remA, 0xFF, (size_t)capH * sizeof(u32), st));
+        uint8_t* din = decA; uint8_t* dout = decB; u32* oin = othA; u32* oout = othB; u32* rin = remA; u32* rout = remB;
+        for (int it = 0;; it++) {
+            if (it > 100000) { err = "step 4: bubble sweep does not settle"; return SAGE2OV_ERR_INTERNAL; }
+            HIPCHK(hipMemsetAsync(dctr, 0, 8 * sizeof(u32), st));
+            hipLaunchKernelGGL(k_s4_bubble, gN, b256, 0, st, g, N, closeLength, rin, din, oin, dout, oout, dctr);
+            u32 ch = 0; if (rd(&ch, 1)) { err = "step 4: counter read failed"; return SAGE2OV_ERR_DEVICE; }
+            if (!ch) break;                                                        // rin is the removal map of exactly these decisions
+            HIPCHK(hipMemsetAsync(rout, 0xFF, (size_t)capH * sizeof(u32), st));
+            hipLaunchKernelGGL(k_s4_bubble_rem, gN, b256, 0, st, g, N, rin, dout, oout, rout);
+            std::swap(din, dout); std::swap(oin, oout); std::swap(rin, rout);
+        }
+        HIPCHK(hipMemsetAsync(dctr, 0, 8 * sizeof(u32), st));
+        hipLaunchKernelGGL(k_s4_count_nz, gN, b256, 0, st, N, din, dctr);
+        if (nh) hipLaunchKernelGGL(k_s4_bubble_apply, dim3(grid_for(nh, 256)), b256, 0, st, g, nh, rin);
+        u32 v = 0; if (rd(&v, 1)) { err = "step 4: counter read failed"; return SAGE2OV_ERR_DEVICE; }
+        *removed = v; return 0;
+    };
+    // ---- main.cpp:150-172
+    int threshold = 0; long long closeValue = 10; u64 contracted = 0, removed = 0, iters = 0, x = 0;
+    int rc;
+    if ((rc = contract_counted(&x))) return rc; contracted += x;
+    if ((rc = dead_ends(threshold, &x))) return rc; removed += x;
+    if ((rc = bubbles(closeValue, &x))) return rc; removed += x;
+    if ((rc = contract_counted(&x))) return rc; contracted += x;
+    for (;;) {
+        u64 a = 0, b = 0, c = 0;
+        if ((rc = dead_ends(threshold, &a))) return rc;
+        if ((rc = bubbles(closeValue, &b))) return rc;
+        if ((rc = contract_counted(&c))) return rc;
+        removed += a + b; contracted += c; iters++;
+        if (a + b + c == 0) break;
+        if (closeValue < 50) closeValue += 10;
+        if (threshold < 3) threshold++;
+    }
+    HIPCHK(hipEventRecord(d->ev[1], st)); HIPCHK(hipStreamSynchronize(st));
+    float ms = 0; hipEventElapsedTime(&ms, d->ev[0], d->ev[1]);
+    out.n_half_edges = nh; out.contracted = contracted; out.removed = removed; out.iterations = iters; out.device_ms = ms; out.N = N64;
+    out.from.resize(nh); out.to.resize(nh); out.len.resize(nh); out.cnt.resize(nh); out.off.resize(nh); out.type.resize(nh); out.alive.resize(nh); out.lists.resize(listUsed);
+    if (nh) {
+        HIPCHK(hipMemcpy(out.from.data(), g.from, nh * sizeof(u32), hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(out.to.data(), g.to, nh * sizeof(u32), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(out.len.data(), g.len, nh * sizeof(u32), hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(out.cnt.data(), g.cnt, nh * sizeof(u32), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(out.off.data(), g.off, nh * sizeof(u32), hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(out.type.data(), g.type, nh, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(out.alive.data(), g.alive, nh, hipMemcpyDeviceToHost));
+    }
+    if (listUsed) HIPCHK(hipMemcpy(out.lists.data(), g.lists, listUsed * sizeof(u64), hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -69,6 +69,7 @@ struct sage2ov_ctx {
     sage2ov_index_stats istats{};
     sage2ov_overlap_stats ostats{};
     std::vector<FinalEdge> edges; bool edgesOnHost = false;
+    SimplifiedGraph g4; bool g4Valid = false;
     double reduce_ms = 0, total_ms = 0;
 
     int fail(int code, const std::string& m) { err = m; return code; }
@@ -711,6 +712,50 @@ int sage2ov_edges_export(sage2ov_ctx* c, sage2ov_edge* out, uint64_t cap) {
     for (size_t x = 0; x < c->edges.size(); x++) { const FinalEdge& e = c->edges[x]; sage2ov_edge o{}; o.from = e.from; o.to = e.to; o.length = e.len; o.length_twin = e.len_twin; o.type = (uint8_t)e.type; out[x] = o; }
     return SAGE2OV_OK;
 }
+// the counterpart of loadOverlapGraphFromFile for a graph of simple edges (overlapGraph.cpp:371-442): take the canonical edge list instead
+// of computing it (`-m 4` on existing files; synthetic graphs in the step-4 tests).  Pairs keep the order given = the order they are pushed.
+int sage2ov_edges_import(sage2ov_ctx* c, const sage2ov_edge* e, uint64_t n) {
+    if (!c || (!e && n)) return SAGE2OV_ERR_ARG;
+    if (!c->dev) return c->fail(SAGE2OV_ERR_DEVICE, "no GPU context");
+    if (!c->organized) return c->fail(SAGE2OV_ERR_ARG, "sage2ov_edges_import: the read set comes first (reads_organize / reads_load)");
+    c->edges.resize(n);
+    for (uint64_t x = 0; x < n; x++) {
+        if (e[x].from == 0 || e[x].to == 0 || e[x].from > c->N || e[x].to > c->N || e[x].type > 3) return c->fail(SAGE2OV_ERR_ARG, "sage2ov_edges_import: read id or edge type out of range");
+        c->edges[x] = FinalEdge{(uint32_t)e[x].from, (uint32_t)e[x].to, e[x].length, e[x].length_twin, e[x].type};
+    }
+    int rc = dev_upload_edges(c->dev, c->edges, c->err); if (rc) return rc;
+    c->ostats.edges = n; c->edgesOnHost = true; c->converted = true; c->g4Valid = false;
+    return SAGE2OV_OK;
+}
+// loadOverlapGraphFromFile (overlapGraph.cpp:371-442) for the graph step 3 writes: simple edges only (list size 0)
+int sage2ov_graph_load(sage2ov_ctx* c, const char* path) {
+    if (!c || !path) return SAGE2OV_ERR_ARG;
+    FILE* f = fopen(path, "rb"); if (!f) return c->fail(SAGE2OV_ERR_IO, std::string("cannot open ") + path);
+    std::string txt; { char buf[1 << 16]; size_t n; while ((n = fread(buf, 1, sizeof buf, f)) > 0) txt.append(buf, n); } fclose(f);
+    const char* p = txt.c_str(); const char* end = p + txt.size();
+    auto num = [&](unsigned long long& v) -> bool {
+        while (p < end && (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r')) p++;
+        if (p >= end || *p < '0' || *p > '9') return false;
+        v = 0; while (p < end && *p >= '0' && *p <= '9') v = v * 10 + (unsigned long long)(*p++ - '0');
+        if (p < end && *p == '.') { p++; while (p < end && *p >= '0' && *p <= '9') p++; }          // the flow column is a float ("0")
+        return true;
+    };
+    unsigned long long gs, nr, avg;
+    if (!num(gs) || !num(nr) || !num(avg)) return c->fail(SAGE2OV_ERR_IO, "bad .graph3 header");
+    std::vector<sage2ov_edge> e;
+    for (;;) {
+        unsigned long long a[7], b[7];
+        if (!num(a[0])) break;
+        for (int x = 1; x < 7; x++) if (!num(a[x])) return c->fail(SAGE2OV_ERR_IO, "bad .graph3 record");
+        for (int x = 0; x < 7; x++) if (!num(b[x])) return c->fail(SAGE2OV_ERR_IO, "bad .graph3 record (twin)");
+        if (a[6] != 0 || b[6] != 0) return c->fail(SAGE2OV_ERR_LIMIT, "sage2ov_graph_load: composite edges (a graph already simplified) are not supported");
+        if (a[0] != b[1] || a[1] != b[0]) return c->fail(SAGE2OV_ERR_IO, "bad .graph3: a record is not followed by its twin");
+        sage2ov_edge o{}; o.from = a[0]; o.to = a[1]; o.type = (uint8_t)a[2]; o.length = (uint32_t)a[4]; o.length_twin = (uint32_t)b[4];
+        e.push_back(o);
+    }
+    c->goodReads = nr; c->totalBP = avg * nr;
+    return sage2ov_edges_import(c, e.data(), e.size());
+}
 int sage2ov_graph_save(sage2ov_ctx* c, const char* path) {                            // overlapGraph.cpp:338-369, :12-20
     if (!c || !path) return SAGE2OV_ERR_ARG; int rc = fetch_edges(c); if (rc) return rc;
     FILE* f = fopen(path, "w"); if (!f) return c->fail(SAGE2OV_ERR_IO, std::string("cannot open ") + path);
@@ -725,6 +770,49 @@ int sage2ov_graph_save(sage2ov_ctx* c, const char* path) {                      
         p = rec(p, e.to, e.from, (unsigned)flip_type_host((int)e.type), e.len_twin);
         o.append(buf, (size_t)(p - buf));
     });
+    fclose(f); return rc;
+}
+
+// ---- step 4
+int sage2ov_graph_simplify(sage2ov_ctx* c) {                                          // main.cpp:139-172
+    if (!c) return SAGE2OV_ERR_ARG;
+    if (!c->dev) return c->fail(SAGE2OV_ERR_DEVICE, "no GPU context: step 4 runs on the device only");
+    if (!c->converted) return c->fail(SAGE2OV_ERR_ARG, "sage2ov_graph_simplify: call sage2ov_overlap_convert first");
+    c->g4Valid = false; c->g4 = SimplifiedGraph();
+    int rc = dev_simplify(c->dev, c->g4, c->err); if (rc) return rc;
+    c->g4Valid = true; return SAGE2OV_OK;
+}
+int sage2ov_simplify_stats_get(const sage2ov_ctx* c, sage2ov_simplify_stats* o) {
+    if (!c || !o || !c->g4Valid) return SAGE2OV_ERR_ARG;
+    const SimplifiedGraph& g = c->g4; uint64_t e = 0, r = 0;
+    for (uint64_t h = 0; h < g.n_half_edges; h += 2) if (g.alive[h]) { e++; r += g.cnt[h]; }
+    o->nodes_contracted = g.contracted; o->removed = g.removed; o->loop_iterations = g.iterations; o->edges = e; o->reads_on_edges = r; o->device_ms = g.device_ms;
+    return SAGE2OV_OK;
+}
+int sage2ov_graph4_save(sage2ov_ctx* c, const char* path) {                           // overlapGraph.cpp:338-369, :12-20
+    if (!c || !path) return SAGE2OV_ERR_ARG;
+    if (!c->g4Valid) return c->fail(SAGE2OV_ERR_ARG, "sage2ov_graph4_save: call sage2ov_graph_simplify first");
+    const SimplifiedGraph& g = c->g4; const uint64_t N = g.N, nh = g.n_half_edges;
+    // a node's list, oldest first = its alive half-edges by ascending index (the writer walks each list from its tail, :356-358)
+    std::vector<uint32_t> offs(N + 2, 0), order;
+    for (uint64_t h = 0; h < nh; h++) if (g.alive[h] && g.from[h] <= g.to[h]) offs[g.from[h] + 1]++;
+    for (uint64_t i = 0; i <= N; i++) offs[i + 1] += offs[i];
+    order.resize(offs[N + 1]);
+    { std::vector<uint32_t> cur(offs.begin(), offs.end() - 1); for (uint64_t h = 0; h < nh; h++) if (g.alive[h] && g.from[h] <= g.to[h]) order[cur[g.from[h]]++] = (uint32_t)h; }
+    FILE* f = fopen(path, "w"); if (!f) return c->fail(SAGE2OV_ERR_IO, std::string("cannot open ") + path);
+    std::vector<char> io(1 << 22); setvbuf(f, io.data(), _IOFBF, io.size());
+    fprintf(f, "0\n%llu\n%llu\n", (unsigned long long)c->goodReads, (unsigned long long)(c->goodReads ? c->totalBP / c->goodReads : 0));
+    auto rec = [&](uint32_t h, std::string& o) {
+        char buf[96]; char* p = put_u(buf, g.from[h]); *p++ = '\t'; p = put_u(p, g.to[h]); *p++ = '\t'; p = put_u(p, g.type[h]); memcpy(p, "\t1\t", 3); p += 3;
+        p = put_u(p, g.len[h]); memcpy(p, "\t0\t", 3); p += 3; p = put_u(p, g.cnt[h]); *p++ = '\n'; o.append(buf, (size_t)(p - buf));
+        for (uint32_t x = 0; x < g.cnt[h]; x++) {
+            const uint64_t e = g.lists[(uint64_t)g.off[h] + x];
+            p = put_u(buf, (unsigned long long)(e & ((1ull << 40) - 1))); *p++ = '\t'; *p++ = (char)('0' + ((e >> 40) & 1)); *p++ = '\t'; *p++ = (char)('0' + ((e >> 41) & 1)); *p++ = '\t';
+            p = put_u(p, (unsigned)((e >> 42) & 0x7FF)); *p++ = '\t'; p = put_u(p, (unsigned)((e >> 53) & 0x7FF)); *p++ = '\n'; o.append(buf, (size_t)(p - buf));
+        }
+        o.push_back('\n');
+    };
+    int rc = write_formatted(c, f, order.size(), 96, [&](uint64_t x, std::string& o) { const uint32_t h = order[x]; rec(h, o); rec(h ^ 1u, o); });
     fclose(f); return rc;
 }
 

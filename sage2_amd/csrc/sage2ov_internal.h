@@ -72,6 +72,13 @@ int dev_append_edges(Device* d, const EdgeCand* e, uint64_t n, std::string& err)
 // sortEconomyGraph + convertGraph: canonical list
 int dev_convert(Device* d, uint64_t* n_final, std::string& err);     // result stays in HBM
 int dev_download_edges(Device* d, std::vector<FinalEdge>& out, std::string& err);
+int dev_upload_edges(Device* d, const std::vector<FinalEdge>& in, std::string& err);
+// step 4 (graph simplification) on the device: the surviving half-edges (pair p = 2p, 2p+1; index = age) and their read lists
+struct SimplifiedGraph {
+    uint64_t N = 0, n_half_edges = 0, contracted = 0, removed = 0, iterations = 0; double device_ms = 0;
+    std::vector<uint32_t> from, to, len, cnt, off; std::vector<uint8_t> type, alive; std::vector<uint64_t> lists;
+};
+int dev_simplify(Device* d, SimplifiedGraph& out, std::string& err);
 void dev_timings(Device* d, DevTimings* t);
 void dev_reset_timings(Device* d);
 int dev_sync(Device* d, std::string& err);

@@ -1,0 +1,108 @@
+"""GPU: step 4 (graph simplification on the device, through the C ABI) against the graphs the reference's own classes hold after their
+step 4 (tests/golden/*.graph4.gz, dumped by oracle/ref_driver.cpp::sage2ref_run_step4) and against the CPU restatement
+(oracle/step4_oracle.cpp) on larger inputs: byte identity of the written file -- edges, read lists and their order."""
+import ctypes, gzip, json, os
+import numpy as np
+import pytest
+import fixtures as fx
+import sage2_amd as s2
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _oracle4():
+    lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "liboracle_step4.so"))
+    lib.orc4_run_files.argtypes = [ctypes.c_char_p, ctypes.c_ulonglong, ctypes.c_char_p, ctypes.POINTER(ctypes.c_ulonglong)]
+    return lib
+
+
+def _first_diff(a: bytes, b: bytes):
+    n = min(len(a), len(b)); x = next((i for i in range(n) if a[i] != b[i]), n)
+    return f"first difference at byte {x} of {len(a)}/{len(b)}: got {a[max(0, x - 120):x + 120]!r} want {b[max(0, x - 120):x + 120]!r}"
+
+
+@pytest.mark.parametrize("name", fx.golden_names())
+def test_graph4_equals_reference_dump(name, tmp_path):
+    m = fx.golden(name); m4 = json.load(open(os.path.join(fx.GOLDEN, name + ".step4.json")))
+    bases, off = fx.make_reads(m["synth"])
+    ctx = s2.Context(m["k"]); ctx.reads_add_ascii(bases, off); ctx.reads_organize(); ctx.run_steps23()
+    ctx.graph_simplify()
+    st = ctx.simplify_stats()
+    out = str(tmp_path / "t.graph4"); ctx.graph4_save(out); ctx.close()
+    want = gzip.open(os.path.join(fx.GOLDEN, name + ".graph4.gz")).read(); got = open(out, "rb").read()
+    assert (st.nodes_contracted, st.removed, st.loop_iterations) == (m4["counters"]["nodes_contracted"], m4["counters"]["removed"], m4["counters"]["loop_iterations"])
+    assert got == want, _first_diff(got, want)
+
+
+@pytest.mark.parametrize("pd,k", [
+    (dict(seed=41, genome_len=300000, n_reads=100000, read_len=150), 40),
+    (dict(seed=42, genome_len=300000, n_reads=100000, read_len=150, err_ppm=2000), 40),
+    (dict(seed=43, genome_len=200000, n_reads=80000, read_len=100, err_ppm=3000, n_repeat_families=6, repeat_copies=8, repeat_len=400), 21),
+    (dict(seed=44, genome_len=150000, n_reads=80000, read_len=120, read_len_min=70, err_ppm=5000), 25),
+])
+def test_graph4_equals_restatement(pd, k, tmp_path):
+    bases, off = fx.make_reads(pd)
+    ctx = s2.Context(k); ctx.reads_add_ascii(bases, off); ctx.reads_organize(); ctx.run_steps23()
+    g3 = str(tmp_path / "t.graph3"); ctx.graph_save(g3)
+    ctx.graph_simplify(); st = ctx.simplify_stats()
+    out = str(tmp_path / "t.graph4"); ctx.graph4_save(out)
+    n = ctx.reads_stats().unique_reads; ctx.close()
+    c = (ctypes.c_ulonglong * 5)(); ref = str(tmp_path / "ref.graph4")
+    assert _oracle4().orc4_run_files(g3.encode(), n, ref.encode(), c) == 0
+    assert (st.nodes_contracted, st.removed, st.loop_iterations) == (c[2], c[3], c[1])
+    got, want = open(out, "rb").read(), open(ref, "rb").read()
+    assert got == want, _first_diff(got, want)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_graph4_on_synthetic_graphs(seed, tmp_path):
+    """graphs the read pipeline never produces on random genomes: cycles, closed chains, parallel chains with and without a direct edge,
+    two-cycles, nodes whose edges do not combine, multi-edges (tests/graphgen.py), imported through sage2ov_edges_import"""
+    import graphgen as gg
+    N, e = gg.random_graph(seed, n_anchor=8 + 3 * seed, n_paths=20 + 6 * seed, max_len=3 + seed % 9, n_cycles=seed % 4, p_bad=0.02 * (seed % 3))
+    rng = np.random.default_rng(seed)
+    reads = set()
+    while len(reads) < N:
+        reads.add("".join(rng.choice(list("ACGT"), size=100)))
+    bases = np.frombuffer("".join(sorted(reads)).encode(), dtype=np.uint8).copy(); off = np.arange(0, (N + 1) * 100, 100, dtype=np.uint64)
+    ctx = s2.Context(40); ctx.reads_add_ascii(bases, off); ctx.reads_organize()
+    assert ctx.reads_stats().unique_reads == N
+    ctx.edges_import(e)
+    g3 = str(tmp_path / "t.graph3"); ctx.graph_save(g3)
+    ctx.graph_simplify(); st = ctx.simplify_stats()
+    out = str(tmp_path / "t.graph4"); ctx.graph4_save(out); ctx.close()
+    c = (ctypes.c_ulonglong * 5)(); ref = str(tmp_path / "ref.graph4")
+    assert _oracle4().orc4_run_files(g3.encode(), N, ref.encode(), c) == 0
+    got, want = open(out, "rb").read(), open(ref, "rb").read()
+    assert (st.nodes_contracted, st.removed, st.loop_iterations) == (c[2], c[3], c[1]), _first_diff(got, want)
+    assert got == want, _first_diff(got, want)
+
+
+def test_graph4_one_million_noisy_reads(tmp_path):
+    """about a million nodes, chains of a few nodes between error branches, several rounds of the loop: against the restatement"""
+    pd = dict(seed=45, genome_len=3000000, n_reads=1000000, read_len=150, err_ppm=1000)
+    bases, off = fx.make_reads(pd)
+    ctx = s2.Context(40); ctx.reads_add_ascii(bases, off); ctx.reads_organize(); ctx.run_steps23()
+    g3 = str(tmp_path / "t.graph3"); ctx.graph_save(g3)
+    ctx.graph_simplify(); st = ctx.simplify_stats()
+    out = str(tmp_path / "t.graph4"); ctx.graph4_save(out)
+    n = ctx.reads_stats().unique_reads; ctx.close()
+    c = (ctypes.c_ulonglong * 5)(); ref = str(tmp_path / "ref.graph4")
+    assert _oracle4().orc4_run_files(g3.encode(), n, ref.encode(), c) == 0
+    assert (st.nodes_contracted, st.removed, st.loop_iterations) == (c[2], c[3], c[1])
+    assert fx.md5_file(out) == fx.md5_file(ref)
+
+
+def test_cli_steps_1_to_4_and_restart_at_4(tmp_path):
+    """`sage2ov -M 4` writes P.graph4 (and P.graph3 with -s); `sage2ov -m 4` on the saved P.reads + P.graph3 writes the same P.graph4"""
+    import subprocess
+    name = "g3_noisy_rep_k21"; m = fx.golden(name)
+    fa = str(tmp_path / "x.fa"); s2.synth_write_fasta(fx.synth_params(m["synth"]), fa)
+    exe = os.path.join(ROOT, "sage2_amd", "sage2ov"); out = str(tmp_path / "out")
+    subprocess.run([exe, "-f", fa, "-k", str(m["k"]), "-o", out, "-p", "t", "-M", "4", "-s"], check=True, stdout=subprocess.DEVNULL)
+    want = gzip.open(os.path.join(fx.GOLDEN, name + ".graph4.gz")).read()
+    assert open(os.path.join(out, "t.graph3"), "rb").read() == fx.golden_graph3(name)
+    assert open(os.path.join(out, "t.graph4"), "rb").read() == want
+    subprocess.run([exe, "-k", str(m["k"]), "-o", out, "-p", "u", "-i", "t", "-m", "4", "-M", "4"], check=True, stdout=subprocess.DEVNULL)
+    assert open(os.path.join(out, "u.graph4"), "rb").read() == want
