@@ -70,6 +70,11 @@ def cpu_baseline(args, s2, fx):
         nov = ctx.overlap_stats().verified_overlaps
         ours = os.path.join(tmp, "ours.graph3")
         ctx.graph_save(ours)
+        ours4, ours4_ms = os.path.join(tmp, "ours.graph4"), None
+        try:
+            ctx.graph_simplify(); ctx.graph4_save(ours4); ours4_ms = ctx.simplify_stats().device_ms
+        except Exception as e:      # noqa
+            log("[bench] step 4 on the sample failed:", repr(e)); ours4 = None
         ctx.close()
         drv = os.path.join(ROOT, "oracle", "_ref", "libsage2ref_driver.so")
         if os.path.exists(drv) and not args.cpu_port:
@@ -86,6 +91,13 @@ def cpu_baseline(args, s2, fx):
             out = dict(value=nov / T, unit="overlaps/s", cores=threads, kind="reference", sample=sample,
                        seconds=dict(index=t[2], initial=t[3], reduce=t[4], sort_convert=t[5]),
                        graph3_identical_to_gpu=bool(same))
+            if hasattr(L, "sage2ref_run_step4") and ours4:
+                # step 4 of the reference on the same sample (its loaders, its loop, its writer), against our P.graph4
+                t4 = (C.c_double * 2)(); c4 = (C.c_ulonglong * 4)()
+                L.sage2ref_run_step4.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_ulonglong)]
+                if L.sage2ref_run_step4(pref.encode(), args.k, threads, (pref + ".graph4").encode(), t4, c4) == 0:
+                    out["step4"] = dict(seconds=t4[1], load_seconds=t4[0], nodes_contracted=int(c4[2]), removed=int(c4[3]), gpu_device_ms=ours4_ms,
+                                        graph4_identical_to_gpu=bool(open(pref + ".graph4", "rb").read() == open(ours4, "rb").read()))
         else:
             import oracle_lib as ol
             bases, off = s2.synth_reads_ascii(p, g)
@@ -130,6 +142,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-step4", action="store_true", help="skip the step-4 (graph simplification) figures reported beside the metric")
     ap.add_argument("--reads", type=int, default=10_000_000)      # BASELINE.json configs[1]
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--k", type=int, default=40)
@@ -282,6 +295,13 @@ def main():
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": a_probe * share,
                          "whole_path_achieved": a_total / (elapsed / args.steps) / 1e9, "whole_path_frac": a_total / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
         }
+        def step4_of(c):
+            """step 4 on the graph the timed steps left in HBM: outside the timed region, two runs, the second reported"""
+            c.graph_simplify(); t4 = time.perf_counter(); c.graph_simplify(); w4 = time.perf_counter() - t4; s4 = c.simplify_stats()
+            return {"device_ms": s4.device_ms, "wall_ms": 1e3 * w4, "nodes_contracted": s4.nodes_contracted, "removed": s4.removed, "loop_iterations": s4.loop_iterations,
+                    "edges_left": s4.edges, "reads_on_edges": s4.reads_on_edges}
+        if world == 1 and not args.no_step4:
+            res["step4"] = step4_of(ctx)
         if world == 1 and not args.no_noisy_variant and args.err_ppm == 0:
             # secondary workload of SURVEY 8(d): the same reads with 0.1 % substitution errors (98 % of the reads then go through the
             # reduce phase); same timed region, two steps
@@ -300,6 +320,8 @@ def main():
             res["noisy_variant"] = {"err_ppm": 1000, "ms_per_step": 1e3 * en, "value": on.verified_overlaps / en, "unit": "overlaps/s", "steps": nsteps,
                                     "unique_reads": cn.reads_stats().unique_reads, "verified_overlaps": on.verified_overlaps, "edges": on.edges,
                                     "unresolved_reads": on.left_to_explore, "phases_ms": {kph: v / nsteps for kph, v in phn.items()}}
+            if not args.no_step4:
+                res["noisy_variant"]["step4"] = step4_of(cn)
             cn.close()
         if world == 1 and not args.no_cpu_baseline:
             ctx.close()

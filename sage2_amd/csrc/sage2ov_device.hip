@@ -12,6 +12,7 @@
 #include <cstring>
 #include <cstdlib>
 #include <vector>
+#include <memory>
 #include "sage2ov.h"
 #include "sage2ov_internal.h"
 
@@ -53,6 +54,7 @@ struct Device {
     // final edges (device resident)
     FinalEdge* final_edges = nullptr; u64 n_final = 0;
     DevTimings tm;
+    void* s4keep = nullptr;      // step 4: the simplified graph stays in HBM until the next call (S4Keep)
     // workspace arena: buffers of the timed path are allocated once and only ever grow (no hipMalloc/hipFree per step)
     struct Buf { void* p = nullptr; size_t cap = 0; };
     Buf ws[WS_COUNT];
@@ -120,6 +122,7 @@ void dev_destroy(Device* d) {
     if (!d) return;
     hipSetDevice(d->ordinal);
     hipStreamSynchronize(d->stream);
+    dev_simplify_release(d);
     free_reads(d); hipFree(d->d_counters);
     for (auto& ev : d->ev) if (ev) hipEventDestroy(ev);
     hipStreamDestroy(d->stream);
@@ -790,13 +793,17 @@ struct S4Mem {                                   // freed on every exit path
 };
 }
 #define S4GET(var, type, n) type* var = mem.get<type>((n), err); if (!var) return SAGE2OV_ERR_NOMEM;
+struct S4Keep { S4Mem mem; S4Graph g; u32 nh = 0; u64 listUsed = 0; };
+void dev_simplify_release(Device* d) { if (d->s4keep) { hipSetDevice(d->ordinal); delete (S4Keep*)d->s4keep; d->s4keep = nullptr; } }
 
 int dev_simplify(Device* d, SimplifiedGraph& out, std::string& err) {
     HIPCHK(hipSetDevice(d->ordinal));
+    dev_simplify_release(d);
+    std::unique_ptr<S4Keep> keep(new S4Keep());
+    S4Mem& mem = keep->mem; S4Graph& g = keep->g;
     const u64 N64 = d->N, np = d->n_final;
     if (2 * np + 2 * (N64 + 1) >= (1ull << 32)) { err = "step 4: too many edges"; return SAGE2OV_ERR_LIMIT; }
     const u32 N = (u32)N64, capH = (u32)(2 * np + 2 * (N64 + 1));
-    S4Mem mem; S4Graph g;
     { S4GET(a, u32, capH) g.from = a; } { S4GET(a, u32, capH) g.to = a; } { S4GET(a, u32, capH) g.len = a; } { S4GET(a, u32, capH) g.cnt = a; } { S4GET(a, u32, capH) g.off = a; }
     { S4GET(a, uint8_t, capH) g.type = a; } { S4GET(a, uint8_t, capH) g.alive = a; }
     { S4GET(a, u32, N + 2) g.deg = a; } { S4GET(a, u32, N + 2) g.adjOff = a; } { S4GET(a, u32, capH) g.adj = a; }
@@ -879,7 +886,7 @@ int dev_simplify(Device* d, SimplifiedGraph& out, std::string& err) {
     // merged nodes of a sweep = nodes with role 1 or 2 (every one of them is one successful mergeEdges)
     auto count_roles = [&](u64* n) -> int {
         HIPCHK(hipMemsetAsync(dctr, 0, 8 * sizeof(u32), st));
-        hipLaunchKernelGGL(k_s4_count_nz, gN, b256, 0, st, N, role, dctr);
+        hipLaunchKernelGGL(k_s4_count, gN, b256, 0, st, N, role, dctr);
         u32 v = 0; if (rd(&v, 1)) { err = "step 4: counter read failed"; return SAGE2OV_ERR_DEVICE; }
         *n = v; return 0;
     };
@@ -919,7 +926,7 @@ int dev_simplify(Device* d, SimplifiedGraph& out, std::string& err) {
             std::swap(din, dout); std::swap(oin, oout); std::swap(rin, rout);
         }
         HIPCHK(hipMemsetAsync(dctr, 0, 8 * sizeof(u32), st));
-        hipLaunchKernelGGL(k_s4_count_nz, gN, b256, 0, st, N, din, dctr);
+        hipLaunchKernelGGL(k_s4_count, gN, b256, 0, st, N, din, dctr);
         if (nh) hipLaunchKernelGGL(k_s4_bubble_apply, dim3(grid_for(nh, 256)), b256, 0, st, g, nh, rin);
         u32 v = 0; if (rd(&v, 1)) { err = "step 4: counter read failed"; return SAGE2OV_ERR_DEVICE; }
         *removed = v; return 0;
@@ -943,15 +950,34 @@ int dev_simplify(Device* d, SimplifiedGraph& out, std::string& err) {
     }
     HIPCHK(hipEventRecord(d->ev[1], st)); HIPCHK(hipStreamSynchronize(st));
     float ms = 0; hipEventElapsedTime(&ms, d->ev[0], d->ev[1]);
-    out.n_half_edges = nh; out.contracted = contracted; out.removed = removed; out.iterations = iters; out.device_ms = ms; out.N = N64;
-    out.from.resize(nh); out.to.resize(nh); out.len.resize(nh); out.cnt.resize(nh); out.off.resize(nh); out.type.resize(nh); out.alive.resize(nh); out.lists.resize(listUsed);
+    S4GET(dstat, u64, 2)
+    HIPCHK(hipMemsetAsync(dstat, 0, 2 * sizeof(u64), st));
+    if (nh) hipLaunchKernelGGL(k_s4_stats, dim3(grid_for(nh / 2 + 1, 256)), b256, 0, st, g, nh, dstat);
+    u64 hs[2] = {0, 0}; HIPCHK(hipMemcpyAsync(hs, dstat, sizeof hs, hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st));
+    out = SimplifiedGraph();
+    out.n_half_edges = nh; out.contracted = contracted; out.removed = removed; out.iterations = iters; out.device_ms = ms; out.N = N64; out.pairs_alive = hs[0]; out.reads_on_edges = hs[1];
+    // the graph stays in HBM (downloaded only when it is written); the work buffers go
+    for (void* p : {(void*)stA, (void*)stB, (void*)tab, (void*)jobs, (void*)jobLen, (void*)jobStart, (void*)remA, (void*)remB, (void*)chain, (void*)g.adj, (void*)cursor, (void*)h0, (void*)h1,
+                    (void*)isNew, (void*)newCnt, (void*)rank, (void*)cntScan, (void*)othA, (void*)othB}) mem.drop(p);
+    g.adj = nullptr;
+    keep->nh = nh; keep->listUsed = listUsed;
+    d->s4keep = keep.release();
+    return 0;
+}
+int dev_simplify_download(Device* d, SimplifiedGraph& out, std::string& err) {
+    HIPCHK(hipSetDevice(d->ordinal));
+    if (!d->s4keep) { err = "step 4: no simplified graph on the device"; return SAGE2OV_ERR_ARG; }
+    if (out.downloaded) return 0;
+    const S4Keep& k = *(S4Keep*)d->s4keep; const S4Graph& g = k.g; const u32 nh = k.nh;
+    out.from.resize(nh); out.to.resize(nh); out.len.resize(nh); out.cnt.resize(nh); out.off.resize(nh); out.type.resize(nh); out.alive.resize(nh); out.lists.resize(k.listUsed);
     if (nh) {
         HIPCHK(hipMemcpy(out.from.data(), g.from, nh * sizeof(u32), hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(out.to.data(), g.to, nh * sizeof(u32), hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(out.len.data(), g.len, nh * sizeof(u32), hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(out.cnt.data(), g.cnt, nh * sizeof(u32), hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(out.off.data(), g.off, nh * sizeof(u32), hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(out.type.data(), g.type, nh, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(out.alive.data(), g.alive, nh, hipMemcpyDeviceToHost));
     }
-    if (listUsed) HIPCHK(hipMemcpy(out.lists.data(), g.lists, listUsed * sizeof(u64), hipMemcpyDeviceToHost));
+    if (k.listUsed) HIPCHK(hipMemcpy(out.lists.data(), g.lists, k.listUsed * sizeof(u64), hipMemcpyDeviceToHost));
+    out.downloaded = true;
     return 0;
 }
 

@@ -784,14 +784,14 @@ int sage2ov_graph_simplify(sage2ov_ctx* c) {                                    
 }
 int sage2ov_simplify_stats_get(const sage2ov_ctx* c, sage2ov_simplify_stats* o) {
     if (!c || !o || !c->g4Valid) return SAGE2OV_ERR_ARG;
-    const SimplifiedGraph& g = c->g4; uint64_t e = 0, r = 0;
-    for (uint64_t h = 0; h < g.n_half_edges; h += 2) if (g.alive[h]) { e++; r += g.cnt[h]; }
+    const SimplifiedGraph& g = c->g4; const uint64_t e = g.pairs_alive, r = g.reads_on_edges;
     o->nodes_contracted = g.contracted; o->removed = g.removed; o->loop_iterations = g.iterations; o->edges = e; o->reads_on_edges = r; o->device_ms = g.device_ms;
     return SAGE2OV_OK;
 }
 int sage2ov_graph4_save(sage2ov_ctx* c, const char* path) {                           // overlapGraph.cpp:338-369, :12-20
     if (!c || !path) return SAGE2OV_ERR_ARG;
     if (!c->g4Valid) return c->fail(SAGE2OV_ERR_ARG, "sage2ov_graph4_save: call sage2ov_graph_simplify first");
+    { int rc = dev_simplify_download(c->dev, c->g4, c->err); if (rc) return rc; }
     const SimplifiedGraph& g = c->g4; const uint64_t N = g.N, nh = g.n_half_edges;
     // a node's list, oldest first = its alive half-edges by ascending index (the writer walks each list from its tail, :356-358)
     std::vector<uint32_t> offs(N + 2, 0), order;

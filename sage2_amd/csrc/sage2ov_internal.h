@@ -75,10 +75,12 @@ int dev_download_edges(Device* d, std::vector<FinalEdge>& out, std::string& err)
 int dev_upload_edges(Device* d, const std::vector<FinalEdge>& in, std::string& err);
 // step 4 (graph simplification) on the device: the surviving half-edges (pair p = 2p, 2p+1; index = age) and their read lists
 struct SimplifiedGraph {
-    uint64_t N = 0, n_half_edges = 0, contracted = 0, removed = 0, iterations = 0; double device_ms = 0;
+    uint64_t N = 0, n_half_edges = 0, contracted = 0, removed = 0, iterations = 0, pairs_alive = 0, reads_on_edges = 0; double device_ms = 0; bool downloaded = false;
     std::vector<uint32_t> from, to, len, cnt, off; std::vector<uint8_t> type, alive; std::vector<uint64_t> lists;
 };
-int dev_simplify(Device* d, SimplifiedGraph& out, std::string& err);
+int dev_simplify(Device* d, SimplifiedGraph& out, std::string& err);             // result stays in HBM
+int dev_simplify_download(Device* d, SimplifiedGraph& out, std::string& err);    // fills the arrays (once)
+void dev_simplify_release(Device* d);
 void dev_timings(Device* d, DevTimings* t);
 void dev_reset_timings(Device* d);
 int dev_sync(Device* d, std::string& err);
