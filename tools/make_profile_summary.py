@@ -3,8 +3,8 @@
 usage: python tools/make_profile_summary.py <round-tag> <stats_dir> <bench_json> <pmc_dir>...
   kernel stats csv -> profiles/<tag>_kernel_stats.csv, the bench line of the same profiled run -> profiles/<tag>_bench_under_rocprof.json,
   PMC passes (one counter group per directory) -> profiles/<tag>_pmc_summary.txt and profiles/probe_traffic.json
-FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB (guide: MI355X_MICROARCH.md, HBM section); the random 64-byte gathers of this
-kernel are not the wide streaming case of the guide's x2 correction, and TCC_EA0_RDREQ x 64 B agrees with FETCH_SIZE as collected.
+FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB (guide: MI355X_MICROARCH.md, HBM section).  Every read request of the probe
+kernel is a 128-byte line (TCC_EA0_RDREQ_128B == TCC_EA0_RDREQ) which FETCH_SIZE tallies at 64 bytes: reads = requests x 128 B.
 """
 import csv, glob, json, os, shutil, sys, collections
 
