@@ -810,7 +810,8 @@ int dev_simplify(Device* d, SimplifiedGraph& out, std::string& err) {
     u64 listCap = std::max<u64>(4 * (N64 + 1), 1 << 16), listUsed = 0;
     { S4GET(a, u64, listCap) g.lists = a; }
     S4GET(cursor, u32, N + 2) S4GET(cont, uint8_t, N + 2) S4GET(forced, uint8_t, N + 2) S4GET(role, uint8_t, N + 2) S4GET(h0, u32, N + 2) S4GET(h1, u32, N + 2)
-    S4GET(stA, S4State, 2 * (size_t)(N + 1)) S4GET(stB, S4State, 2 * (size_t)(N + 1))
+    S4GET(stA, S4State, 2 * (size_t)(N + 1)) S4GET(stB, S4State, 2 * (size_t)(N + 1)) S4GET(stC, S4State, 2 * (size_t)(N + 1))
+    S4GET(spFlag, u32, 2 * (size_t)(N + 1) + 2) S4GET(spPos, u32, 2 * (size_t)(N + 1) + 2) S4GET(spList, u32, 2 * (size_t)(N + 1) + 2)
     S4GET(isNew, u32, N + 2) S4GET(newCnt, u32, N + 2) S4GET(rank, u32, N + 2) S4GET(cntScan, u32, N + 2)
     S4GET(chain, S4Chain, capH) S4GET(jobs, S4Job, 4 * (size_t)(N + 1)) S4GET(jobLen, u32, 4 * (size_t)(N + 1)) S4GET(jobStart, u32, 4 * (size_t)(N + 1))
     S4GET(decA, uint8_t, N + 2) S4GET(decB, uint8_t, N + 2) S4GET(othA, u32, N + 2) S4GET(othB, u32, N + 2) S4GET(remA, u32, capH) S4GET(remB, u32, capH)
@@ -823,7 +824,10 @@ int dev_simplify(Device* d, SimplifiedGraph& out, std::string& err) {
     HIPCHK(hipEventRecord(d->ev[0], st));
     if (np) hipLaunchKernelGGL(k_s4_init, dim3(grid_for(np, 256)), dim3(256), 0, st, d->final_edges, (u64)np, g);
     auto rd = [&](u32* v, int n) -> int { return hipMemcpyAsync(v, dctr, n * sizeof(u32), hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess ? 0 : -1; };
+    bool adjValid = false;                                                         // the lists only change when a sweep changes the graph
     auto adjacency = [&]() -> int {
+        if (adjValid) return 0;
+        adjValid = true;
         HIPCHK(hipMemsetAsync(g.deg, 0, (N + 2) * sizeof(u32), st)); HIPCHK(hipMemsetAsync(cursor, 0, (N + 2) * sizeof(u32), st));
         if (nh) hipLaunchKernelGGL(k_s4_degree, dim3(grid_for(nh, 256)), dim3(256), 0, st, g, nh);
         u64 tot = 0; int rc = scan_u32(d, g.deg, (u64)N + 1, g.adjOff, &tot, err); if (rc) return rc;
@@ -837,23 +841,48 @@ int dev_simplify(Device* d, SimplifiedGraph& out, std::string& err) {
     auto contract = [&](u64* merged) -> int {
         int rc = adjacency(); if (rc) return rc;
         HIPCHK(hipMemsetAsync(forced, 0, N + 2, st));
-        const S4State* fin = nullptr;
+        const S4State* fin = nullptr; bool plainJumping = getenv("SAGE2OV_S4_PLAIN_JUMPING") != nullptr;
         for (int round = 0;; round++) {
             if (round > 64) { err = "step 4: chain promotion does not settle"; return SAGE2OV_ERR_INTERNAL; }
             hipLaunchKernelGGL(k_s4_contractible, gN, b256, 0, st, g, N, forced, cont, h0, h1);
             hipLaunchKernelGGL(k_s4_state_init, gS, b256, 0, st, g, N, cont, h0, h1, stA);
-            S4State* a = stA; S4State* b = stB;
-            for (int r = 0; r < jumpRounds; r++) {                                   // stops as soon as every state has reached its chain end (cycles never do)
-                HIPCHK(hipMemsetAsync(dctr, 0, sizeof(u32), st));
-                hipLaunchKernelGGL(k_s4_jump, gS, b256, 0, st, N, cont, a, b, dctr); std::swap(a, b);
-                u32 open = 0; if (rd(&open, 1)) { err = "step 4: counter read failed"; return SAGE2OV_ERR_DEVICE; }
-                if (!open) break;
+            bool ranked = false;
+            if (!plainJumping) {                                                     // O(n): splitters, jumping over the splitter states only, hand-out
+                hipLaunchKernelGGL(k_s4_split_flags, gS, b256, 0, st, N, cont, spFlag);
+                u64 nS = 0; rc = scan_u32(d, spFlag, 2 * ((u64)N + 1), spPos, &nS, err); if (rc) return rc;
+                HIPCHK(hipMemsetAsync(dctr, 0, 8 * sizeof(u32), st));
+                if (nS) {
+                    hipLaunchKernelGGL(k_s4_split_list, gS, b256, 0, st, N, spFlag, spPos, spList);
+                    hipLaunchKernelGGL(k_s4_walk_a, dim3(grid_for(nS, 64)), dim3(64), 0, st, spList, (u32)nS, stA, stB, dctr + 2);
+                }
+                S4State* a = stB; S4State* b = stC;
+                for (int r = 0; nS && r < jumpRounds; r++) {
+                    HIPCHK(hipMemsetAsync(dctr, 0, sizeof(u32), st));
+                    hipLaunchKernelGGL(k_s4_jump_list, dim3(grid_for(nS, 256)), b256, 0, st, spList, (u32)nS, a, b, dctr); std::swap(a, b);
+                    u32 open = 0; if (rd(&open, 1)) { err = "step 4: counter read failed"; return SAGE2OV_ERR_DEVICE; }
+                    if (!open) break;
+                }
+                HIPCHK(hipMemsetAsync(b, 0xFF, 2 * (size_t)(N + 1) * sizeof(S4State), st));
+                hipLaunchKernelGGL(k_s4_walk_b, dim3(grid_for(2 * ((u64)N + 1), 64)), dim3(64), 0, st, N, cont, stA, a, b, dctr + 2);
+                u32 cz[3] = {0, 0, 0}; if (rd(cz, 3)) { err = "step 4: counter read failed"; return SAGE2OV_ERR_DEVICE; }
+                if (cz[2]) plainJumping = true; else { fin = b; ranked = true; }
             }
-            fin = a;
+            if (!ranked) {
+                S4State* a = stA; S4State* b = stB;
+                for (int r = 0; r < jumpRounds; r++) {                               // stops as soon as every state has reached its chain end (cycles never do)
+                    HIPCHK(hipMemsetAsync(dctr, 0, sizeof(u32), st));
+                    hipLaunchKernelGGL(k_s4_jump, gS, b256, 0, st, N, cont, a, b, dctr); std::swap(a, b);
+                    u32 open = 0; if (rd(&open, 1)) { err = "step 4: counter read failed"; return SAGE2OV_ERR_DEVICE; }
+                    if (!open) break;
+                }
+                fin = a;
+            }
             HIPCHK(hipMemsetAsync(tab, 0xFF, sizeof(S4Pair) << tabBits, st)); HIPCHK(hipMemsetAsync(dctr, 0, 8 * sizeof(u32), st));
             hipLaunchKernelGGL(k_s4_chain, gN, b256, 0, st, g, N, cont, fin, role, tab, tabMask, dctr);
             hipLaunchKernelGGL(k_s4_parallel, gN, b256, 0, st, g, N, fin, role, tab, tabMask, dctr);
-            u32 promoted = 0; if (rd(&promoted, 1)) { err = "step 4: counter read failed"; return SAGE2OV_ERR_DEVICE; }
+            u32 pz[2] = {0, 0}; if (rd(pz, 2)) { err = "step 4: counter read failed"; return SAGE2OV_ERR_DEVICE; }
+            if (pz[1]) { if (plainJumping) { err = "step 4: chain states left unwritten"; return SAGE2OV_ERR_INTERNAL; } plainJumping = true; round--; continue; }   // a cycle without a splitter
+            const u32 promoted = pz[0];
             if (!promoted) break;
             hipLaunchKernelGGL(k_s4_promote, gN, b256, 0, st, N, role, forced);
         }
@@ -879,7 +908,7 @@ int dev_simplify(Device* d, SimplifiedGraph& out, std::string& err) {
             u64 total = 0; rc = scan_u32(d, jobLen, nj, jobStart, &total, err); if (rc) return rc;
             if (total) hipLaunchKernelGGL(k_s4_copy, dim3(grid_for(total, 256)), b256, 0, st, jobs, nj, jobStart, (u64)total, g.lists);
         }
-        nh += (u32)(2 * nNew); listUsed += 2 * nList;
+        nh += (u32)(2 * nNew); listUsed += 2 * nList; adjValid = false;
         *merged = nNew;                                                            // (non-zero: the caller counts the merged nodes)
         return 0;
     };
@@ -908,7 +937,7 @@ int dev_simplify(Device* d, SimplifiedGraph& out, std::string& err) {
         hipLaunchKernelGGL(k_s4_count, gN, b256, 0, st, N, in, dctr);
         if (nh) hipLaunchKernelGGL(k_s4_dead_apply, dim3(grid_for(nh, 256)), b256, 0, st, g, nh, in);
         u32 v = 0; if (rd(&v, 1)) { err = "step 4: counter read failed"; return SAGE2OV_ERR_DEVICE; }
-        *removed = v; return 0;
+        *removed = v; if (v) adjValid = false; return 0;
     };
     // ---- removeBubbles (simplification.cpp:118-194)
     auto bubbles = [&](long long closeLength, u64* removed) -> int {
@@ -929,7 +958,7 @@ int dev_simplify(Device* d, SimplifiedGraph& out, std::string& err) {
         hipLaunchKernelGGL(k_s4_count, gN, b256, 0, st, N, din, dctr);
         if (nh) hipLaunchKernelGGL(k_s4_bubble_apply, dim3(grid_for(nh, 256)), b256, 0, st, g, nh, rin);
         u32 v = 0; if (rd(&v, 1)) { err = "step 4: counter read failed"; return SAGE2OV_ERR_DEVICE; }
-        *removed = v; return 0;
+        *removed = v; if (v) adjValid = false; return 0;
     };
     // ---- main.cpp:150-172
     int threshold = 0; long long closeValue = 10; u64 contracted = 0, removed = 0, iters = 0, x = 0;
@@ -957,7 +986,7 @@ int dev_simplify(Device* d, SimplifiedGraph& out, std::string& err) {
     out = SimplifiedGraph();
     out.n_half_edges = nh; out.contracted = contracted; out.removed = removed; out.iterations = iters; out.device_ms = ms; out.N = N64; out.pairs_alive = hs[0]; out.reads_on_edges = hs[1];
     // the graph stays in HBM (downloaded only when it is written); the work buffers go
-    for (void* p : {(void*)stA, (void*)stB, (void*)tab, (void*)jobs, (void*)jobLen, (void*)jobStart, (void*)remA, (void*)remB, (void*)chain, (void*)g.adj, (void*)cursor, (void*)h0, (void*)h1,
+    for (void* p : {(void*)stA, (void*)stB, (void*)stC, (void*)spFlag, (void*)spPos, (void*)spList, (void*)tab, (void*)jobs, (void*)jobLen, (void*)jobStart, (void*)remA, (void*)remB, (void*)chain, (void*)g.adj, (void*)cursor, (void*)h0, (void*)h1,
                     (void*)isNew, (void*)newCnt, (void*)rank, (void*)cntScan, (void*)othA, (void*)othB}) mem.drop(p);
     g.adj = nullptr;
     keep->nh = nh; keep->listUsed = listUsed;

@@ -106,3 +106,27 @@ def test_cli_steps_1_to_4_and_restart_at_4(tmp_path):
     assert open(os.path.join(out, "t.graph4"), "rb").read() == want
     subprocess.run([exe, "-k", str(m["k"]), "-o", out, "-p", "u", "-i", "t", "-m", "4", "-M", "4"], check=True, stdout=subprocess.DEVNULL)
     assert open(os.path.join(out, "u.graph4"), "rb").read() == want
+
+
+def test_plain_jumping_path_equals_splitter_ranking(monkeypatch, tmp_path):
+    """the chain ranking has two forms (splitter-based O(n); plain pointer jumping as the fallback for cycles without a splitter and
+    for over-long stretches): same file from both"""
+    import graphgen as gg
+    outs = {}
+    for mode in ("default", "plain"):
+        if mode == "plain":
+            monkeypatch.setenv("SAGE2OV_S4_PLAIN_JUMPING", "1")
+        N, e = gg.random_graph(77, n_anchor=200, n_paths=700, max_len=90, n_cycles=12, p_bad=0.01)
+        rng = np.random.default_rng(77); reads = set()
+        while len(reads) < N:
+            reads.add("".join(rng.choice(list("ACGT"), size=100)))
+        bases = np.frombuffer("".join(sorted(reads)).encode(), dtype=np.uint8).copy(); off = np.arange(0, (N + 1) * 100, 100, dtype=np.uint64)
+        ctx = s2.Context(40); ctx.reads_add_ascii(bases, off); ctx.reads_organize(); ctx.edges_import(e)
+        g3 = str(tmp_path / f"{mode}.graph3"); ctx.graph_save(g3)
+        ctx.graph_simplify(); out = str(tmp_path / f"{mode}.graph4"); ctx.graph4_save(out); ctx.close()
+        outs[mode] = open(out, "rb").read()
+    c = (ctypes.c_ulonglong * 5)(); ref = str(tmp_path / "ref.graph4")
+    assert _oracle4().orc4_run_files(g3.encode(), N, ref.encode(), c) == 0
+    want = open(ref, "rb").read()
+    assert outs["default"] == want, _first_diff(outs["default"], want)
+    assert outs["plain"] == want, _first_diff(outs["plain"], want)
