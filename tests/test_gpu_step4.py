@@ -130,3 +130,51 @@ def test_plain_jumping_path_equals_splitter_ranking(monkeypatch, tmp_path):
     want = open(ref, "rb").read()
     assert outs["default"] == want, _first_diff(outs["default"], want)
     assert outs["plain"] == want, _first_diff(outs["plain"], want)
+
+
+def _run_imported(N, e, tmp_path, tag):
+    rng = np.random.default_rng(N); reads = set()
+    while len(reads) < N:
+        reads.add("".join(rng.choice(list("ACGT"), size=60)))
+    bases = np.frombuffer("".join(sorted(reads)).encode(), dtype=np.uint8).copy(); off = np.arange(0, (N + 1) * 60, 60, dtype=np.uint64)
+    ctx = s2.Context(40); ctx.reads_add_ascii(bases, off); ctx.reads_organize(); ctx.edges_import(e)
+    g3 = str(tmp_path / f"{tag}.graph3"); ctx.graph_save(g3)
+    ctx.graph_simplify(); st = ctx.simplify_stats(); out = str(tmp_path / f"{tag}.graph4"); ctx.graph4_save(out); ctx.close()
+    c = (ctypes.c_ulonglong * 5)(); ref = str(tmp_path / f"{tag}.ref4")
+    assert _oracle4().orc4_run_files(g3.encode(), N, ref.encode(), c) == 0
+    got, want = open(out, "rb").read(), open(ref, "rb").read()
+    assert (st.nodes_contracted, st.removed, st.loop_iterations) == (c[2], c[3], c[1])
+    assert got == want, _first_diff(got, want)
+    return st
+
+
+def _ring(n, seed, closed):
+    """n nodes in one path (or one cycle) of forward-forward overlaps, ids scattered"""
+    import graphgen as gg
+    rng = np.random.default_rng(seed); perm = rng.permutation(n) + 1
+    rows = []
+    for j in range(n if closed else n - 1):
+        a, b = int(perm[j]), int(perm[(j + 1) % n]); t = 3
+        if a > b: a, b, t = b, a, 0
+        rows.append((a, b, t, int(rng.integers(1, 100))))
+    rows.sort()
+    e = np.zeros(len(rows), dtype=gg.EDGE_DTYPE)
+    for i, (a, b, t, ln) in enumerate(rows):
+        e[i]["from"], e[i]["to"], e[i]["type"], e[i]["length"], e[i]["length_twin"] = a, b, t, ln, ln
+    return e
+
+
+def test_one_long_chain_and_one_big_cycle(tmp_path):
+    """a linear genome is one chain (everything but the two ends is contracted), a circular one is a cycle without any branching node:
+    its three largest ids survive (simplification.cpp:27-34 stops the sweep at a triangle)"""
+    n = 200000
+    st = _run_imported(n, _ring(n, 5, closed=False), tmp_path, "chain")
+    assert st.nodes_contracted == n - 2 and st.edges == 1
+    st = _run_imported(n, _ring(n, 6, closed=True), tmp_path, "cycle")
+    assert st.nodes_contracted == n - 3 and st.edges == 3
+
+
+def test_graph_without_edges(tmp_path):
+    import graphgen as gg
+    st = _run_imported(500, np.zeros(0, dtype=gg.EDGE_DTYPE), tmp_path, "empty")
+    assert st.edges == 0 and st.nodes_contracted == 0
