@@ -350,7 +350,7 @@ static ProbeArgs base_args(Device* d) {
     ProbeArgs A; memset(&A, 0, sizeof A);
     A.reads = d->reads; A.N = d->N; A.S = d->S; A.k = d->k; A.h = d->h; A.slots = d->slots; A.T = d->T; A.csr = d->csr; A.seed = d->seed;
     A.right = d->right; A.left = d->left; A.conn = d->conn; A.cflag = d->cflag; A.status = d->status; A.counters = d->d_counters;
-    A.mi1 = d->mi1; A.TL = d->TL; A.krec = d->krec;
+    A.mi1 = d->mi1; A.TL = d->TL; A.krec = d->krec; A.uniL = d->uniL;
     return A;
 }
 
