@@ -178,3 +178,22 @@ def test_graph_without_edges(tmp_path):
     import graphgen as gg
     st = _run_imported(500, np.zeros(0, dtype=gg.EDGE_DTYPE), tmp_path, "empty")
     assert st.edges == 0 and st.nodes_contracted == 0
+
+
+def test_hub_with_thousands_of_edges(tmp_path):
+    """a node with 3000 edges (a collapsed repeat): its list is heap-sorted; tips of one and two nodes around it"""
+    import graphgen as gg
+    rng = np.random.default_rng(9); n_spokes = 3000
+    N = 1 + 2 * n_spokes; perm = rng.permutation(N) + 1; hub = int(perm[0]); rows = set()
+    for j in range(n_spokes):
+        a, b = int(perm[1 + 2 * j]), int(perm[2 + 2 * j])
+        t1 = int(rng.integers(0, 4)); x, y, t = (hub, a, t1) if hub < a else (a, hub, {0: 3, 3: 0, 1: 1, 2: 2}[t1])
+        rows.add((x, y, t, int(rng.integers(1, 60))))
+        if j % 3:
+            t2 = int(rng.integers(0, 4)); x, y, t = (a, b, t2) if a < b else (b, a, {0: 3, 3: 0, 1: 1, 2: 2}[t2])
+            rows.add((x, y, t, int(rng.integers(1, 60))))
+    rows = sorted(rows)
+    e = np.zeros(len(rows), dtype=gg.EDGE_DTYPE)
+    for i, (a, b, t, ln) in enumerate(rows):
+        e[i]["from"], e[i]["to"], e[i]["type"], e[i]["length"], e[i]["length_twin"] = a, b, t, ln, ln
+    _run_imported(N, e, tmp_path, "hub")
