@@ -15,6 +15,10 @@
 #include <vector>
 #include <omp.h>
 #include <sched.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include "sage2ov.h"
 #include "sage2ov_internal.h"
 
@@ -115,8 +119,9 @@ struct CodeInit { CodeInit() { memset(g_code, 255, 256); g_code['A'] = g_code['a
 
 // minimal FASTA/FASTQ(.gz) record reader with kseq-like rules (fastAQReader.cpp:16-45)
 struct SeqFile {
-    gzFile fp = nullptr; std::vector<char> buf; size_t pos = 0, end = 0; bool eof = false;
-    bool open(const char* p) { fp = gzopen(p, "r"); if (fp) gzbuffer(fp, 1 << 20); buf.resize(8 << 20); return fp != nullptr; }
+    gzFile fp = nullptr; std::vector<char> buf; size_t pos = 0, end = 0; bool eof = false; const char* win = nullptr;   // win: the current window (buf, or a mapped range)
+    bool open(const char* p) { fp = gzopen(p, "r"); if (fp) gzbuffer(fp, 1 << 20); buf.resize(8 << 20); win = buf.data(); return fp != nullptr; }
+    void open_range(const char* b, size_t n) { win = b; pos = 0; end = n; eof = true; }        // parse a range of a mapped file: one window, never refilled
     ~SeqFile() { if (fp) gzclose(fp); }
     bool refill() { if (eof) return false; int n = gzread(fp, buf.data(), (unsigned)buf.size()); if (n <= 0) { eof = true; return false; } end = (size_t)n; pos = 0; return true; }
     // next line (without the line end) appended to `s`; lines are found with memchr on the 8 MB window
@@ -125,8 +130,8 @@ struct SeqFile {
         for (;;) {
             if (pos >= end && !refill()) break;
             any = true;
-            const char* b = buf.data() + pos; const char* nl = (const char*)memchr(b, '\n', end - pos);
-            if (nl) { s.append(b, (size_t)(nl - b)); pos = (size_t)(nl - buf.data()) + 1; break; }
+            const char* b = win + pos; const char* nl = (const char*)memchr(b, '\n', end - pos);
+            if (nl) { s.append(b, (size_t)(nl - b)); pos = (size_t)(nl - win) + 1; break; }
             s.append(b, end - pos); pos = end;
         }
         if (!s.empty() && s.back() == '\r') s.pop_back();
@@ -151,8 +156,82 @@ struct SeqFile {
     }
 };
 
+// A plain (uncompressed) single file is mapped and cut at record starts into chunks that the threads parse, filter and pack
+// independently -- the read ids do not depend on the input order (they are ranks after the sort).  FASTA: a '>' at a line start is
+// always a header.  FASTQ: a quality line may start with '@' as well; in the four-line form a line starting with '@' is a header iff
+// the line two below starts with '+', and every chunk is parsed strictly as four-line records (equal sequence and quality lengths).
+// Anything else -- multi-line FASTQ, a file that is neither, a chunk that does not parse -- returns false and the sequential reader
+// below takes the whole file.
+static bool add_plain_file_parallel(sage2ov_ctx* c, const char* path) {
+    const int fd = ::open(path, O_RDONLY); if (fd < 0) return false;
+    struct stat sb; if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode) || sb.st_size < (1 << 20)) { ::close(fd); return false; }
+    const size_t size = (size_t)sb.st_size;
+    const char* m = (const char*)mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0); ::close(fd);
+    if (m == MAP_FAILED) return false;
+    struct Unmap { const char* p; size_t n; ~Unmap() { munmap((void*)p, n); } } um{m, size};
+    madvise((void*)m, size, MADV_SEQUENTIAL);
+    if ((unsigned char)m[0] == 0x1f && (unsigned char)m[1] == 0x8b) return false;                          // gzip
+    const char kind = m[0]; if (kind != '>' && kind != '@') return false;
+    auto line_start_after = [&](size_t p) -> size_t { const char* nl = (const char*)memchr(m + p, '\n', size - p); return nl ? (size_t)(nl - m) + 1 : size; };
+    auto boundary = [&](size_t from) -> size_t {                                                        // first record start at or after `from` (a line start)
+        size_t p = from == 0 ? 0 : line_start_after(from - 1);
+        while (p < size) {
+            if (m[p] == kind) {
+                if (kind == '>') return p;
+                const size_t l1 = line_start_after(p), l2 = l1 < size ? line_start_after(l1) : size;
+                if (l2 < size && m[l2] == '+') return p;
+            }
+            p = line_start_after(p);
+        }
+        return size;
+    };
+    const int nt = io_threads(c);
+    const size_t nchunks = std::max<size_t>((size_t)nt, std::min<size_t>(4096, size >> 24));
+    std::vector<size_t> cut(nchunks + 1); cut[0] = 0; cut[nchunks] = size;
+    for (size_t x = 1; x < nchunks; x++) cut[x] = std::max(cut[x - 1], boundary((size * x) / nchunks));
+    struct Part { std::vector<uint64_t> pool, off; std::vector<uint16_t> lens; uint64_t good = 0, bp = 0, small = 0, records = 0; };
+    std::vector<Part> parts(nt); bool bad = false;
+    #pragma omp parallel num_threads(nt)
+    {
+        Part& P = parts[omp_get_thread_num()]; std::string seq; std::vector<uint8_t> codes;
+        #pragma omp for schedule(dynamic, 1)
+        for (int64_t x = 0; x < (int64_t)nchunks; x++) {
+            if (cut[x] >= cut[x + 1]) continue;
+            auto stage = [&](const char* b, size_t L) { codes.resize(L); for (size_t i = 0; i < L; i++) codes[i] = g_code[(unsigned char)b[i]]; stage_codes(c, codes.data(), (int)L, P.pool, P.off, P.lens, P.good, P.bp, P.small); P.records++; };
+            if (kind == '>') {
+                SeqFile f; f.open_range(m + cut[x], cut[x + 1] - cut[x]); size_t len = 0;
+                for (;;) { seq.clear(); if (!f.next(seq, len)) break; stage(seq.data(), len); }
+            } else {                                                                                    // strict four-line FASTQ
+                size_t p = cut[x]; const size_t e = cut[x + 1];
+                auto trimmed = [&](size_t a, size_t b) { size_t n = b - a; if (n && m[b - 1] == '\n') n--; if (n && m[a + n - 1] == '\r') n--; return n; };
+                while (p < e) {
+                    const size_t l1 = line_start_after(p), l2 = l1 < e ? line_start_after(l1) : e, l3 = l2 < e ? line_start_after(l2) : e, l4 = l3 < e ? line_start_after(l3) : e;
+                    const size_t ns = trimmed(l1, l2), nq = trimmed(l3, l4);
+                    bool ws = false; for (size_t i = 0; i < ns; i++) ws |= (unsigned char)m[l1 + i] <= ' ';
+                    if (m[p] != '@' || l2 >= e || m[l2] != '+' || ns != nq || ns == 0 || ws) {
+                        #pragma omp atomic write
+                        bad = true;
+                        break;
+                    }
+                    stage(m + l1, ns); p = l4;
+                }
+            }
+        }
+    }
+    if (bad) return false;
+    for (Part& P : parts) {
+        const uint64_t base = c->pool.size();
+        c->pool.insert(c->pool.end(), P.pool.begin(), P.pool.end());
+        for (uint64_t o : P.off) c->poolOff.push_back(base + o);
+        c->poolLen.insert(c->poolLen.end(), P.lens.begin(), P.lens.end());
+        c->goodReads += P.good; c->totalBP += P.bp; c->smallReads += P.small; c->totalReads += P.records;
+    }
+    return true;
+}
+
 // records are split sequentially (cheap: memchr), filtered and packed by all threads in batches
 int add_files(sage2ov_ctx* c, const char* p1, const char* p2) {
+    if (!(p2 && *p2) && !getenv("SAGE2OV_SEQUENTIAL_READER") && add_plain_file_parallel(c, p1)) return SAGE2OV_OK;
     SeqFile f1, f2; if (!f1.open(p1)) return c->fail(SAGE2OV_ERR_IO, std::string("cannot open ") + p1);
     const bool two = p2 && *p2; if (two && !f2.open(p2)) return c->fail(SAGE2OV_ERR_IO, std::string("cannot open ") + p2);
     const int nt = io_threads(c);

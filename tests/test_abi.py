@@ -146,3 +146,43 @@ def test_reference_continues_from_graph4(name, tmp_path):
     for suffix in suffixes:
         a, b = os.path.join(out, "t2" + suffix), os.path.join(full, "t" + suffix)
         assert os.path.exists(a) and os.path.exists(b) and open(a, "rb").read() == open(b, "rb").read(), suffix
+
+
+def _export(path, k, sequential, monkeypatch):
+    if sequential:
+        monkeypatch.setenv("SAGE2OV_SEQUENTIAL_READER", "1")
+    else:
+        monkeypatch.delenv("SAGE2OV_SEQUENTIAL_READER", raising=False)
+    c = s2.Context(k, device=-2); c.reads_add_file(path); c.reads_organize()
+    st = c.reads_stats(); out = c.reads_export(); c.close()
+    return out, (st.total_reads, st.good_reads, st.unique_reads, st.total_bp)
+
+
+@pytest.mark.parametrize("form", ["fasta", "fasta_multiline_crlf", "fastq", "fastq_at_quality", "fastq_multiline", "fastq_bad_record"])
+def test_parallel_file_reader_equals_sequential_reader(form, tmp_path, monkeypatch):
+    """files above 1 MB are mapped, cut at record starts and parsed by all threads (sage2ov_host.cpp::add_plain_file_parallel); multi-line
+    FASTQ and anything that does not parse strictly fall back to the sequential reader -- same read set, same counters, either way"""
+    rng = np.random.default_rng(3)
+    n, L = 40000, 100
+    seqs = ["".join(rng.choice(list("ACGTacgtN"), p=[.2475, .2475, .2475, .2475, .00225, .00225, .00225, .00225, .001], size=L - int(rng.integers(0, 30)))) for _ in range(n)]
+    path = str(tmp_path / ("x.fq" if form.startswith("fastq") else "x.fa"))
+    with open(path, "w", newline="") as f:
+        for i, s in enumerate(seqs):
+            if form == "fasta":
+                f.write(f">r{i}\n{s}\n")
+            elif form == "fasta_multiline_crlf":
+                f.write(f">r{i} x\r\n{s[:37]}\r\n{s[37:]}\r\n")
+            elif form == "fastq":
+                f.write(f"@r{i}\n{s}\n+\n{'I' * len(s)}\n")
+            elif form == "fastq_at_quality":          # quality lines that start with '@' (and '+' lines that repeat the name)
+                f.write(f"@r{i}\n{s}\n+r{i}\n@{'+' * (len(s) - 1)}\n")
+            elif form == "fastq_multiline":
+                f.write(f"@r{i}\n{s[:50]}\n{s[50:]}\n+\n{'I' * 50}\n{'I' * (len(s) - 50)}\n")
+            else:                                      # one record in the middle with a short quality line: not strict four-line
+                q = "I" * (len(s) - (3 if i == n // 2 else 0))
+                f.write(f"@r{i}\n{s}\n+\n{q}\n")
+    assert os.path.getsize(path) > (1 << 20)
+    (pa, la, fa), sa = _export(path, 21, False, monkeypatch)
+    (pb, lb, fb), sb = _export(path, 21, True, monkeypatch)
+    assert sa == sb and sa[1] > 0.5 * n
+    assert np.array_equal(pa, pb) and np.array_equal(la, lb) and np.array_equal(fa, fb)
