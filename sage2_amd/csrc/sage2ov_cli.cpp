@@ -82,7 +82,7 @@ int main(int argc, char* argv[]) {
             auto s = loaderObj.stats();
             logStream << "\tTotal reads: " << s.total_reads << "\n\tGood reads: " << s.good_reads << "\n\tNumber of unique reads: " << s.unique_reads
                       << "\n\tAverage read length: " << s.average_read_length << "\n\tStep 1 in " << now() - t0 << " sec.\n";
-            if (lastStep == 1 || saveAll) loaderObj.saveReadsInFile(outputDir + prefixName + ".reads");
+            if (lastStep == 1 || saveAll) { double tw = now(); loaderObj.saveReadsInFile(outputDir + prefixName + ".reads"); logStream << "\t" << prefixName << ".reads written in " << now() - tw << " sec.\n"; }
         } else {
             loaderObj.loadReadsFromFile(outputDir + inputPrefix + ".reads");                 // main.cpp:70-74 / :101-104
             logStream << "\tNumber of unique reads: " << loaderObj.numberOfUniqueReads << " (loaded)\n";
@@ -93,7 +93,7 @@ int main(int argc, char* argv[]) {
             logStream << "STEP 4: simplify overlap graph\n\t   Nodes removed: " << ss.nodes_contracted << "\n\tDead ends and bubbles removed: " << ss.removed
                       << "\n\tLoop iterations: " << ss.loop_iterations << "\n\tEdges left: " << ss.edges << " carrying " << ss.reads_on_edges << " reads\n\tStep 4 in " << now() - t4
                       << " sec (device " << ss.device_ms / 1000.0 << ").\n";
-            graphObj.saveSimplifiedGraphInFile(outputDir + prefixName + ".graph4");          // the file step 5 loads (main.cpp:196)
+            { double tw = now(); graphObj.saveSimplifiedGraphInFile(outputDir + prefixName + ".graph4"); logStream << "\t" << prefixName << ".graph4 written in " << now() - tw << " sec.\n"; }   // the file step 5 loads (main.cpp:196)
         };
         if (minStep == 4) {                                                                   // main.cpp:141-148
             OverlapGraph graphObj(&loaderObj);
@@ -106,7 +106,7 @@ int main(int argc, char* argv[]) {
             logStream << "STEP 2: building hash table\n\t         Hash string length: " << is.hash_string_length << "\n\t            Hash table size: " << is.slots
                       << "\n\t Number of hash elements over threshold: " << is.long_buckets << "\n\tStep 2 in " << now() - t0 << " sec.\n";
             if (lastStep == 2) {
-                if (minStep == 1 && !saveAll) loaderObj.saveReadsInFile(outputDir + prefixName + ".reads");
+                if (minStep == 1 && !saveAll) { double tw = now(); loaderObj.saveReadsInFile(outputDir + prefixName + ".reads"); logStream << "\t" << prefixName << ".reads written in " << now() - tw << " sec.\n"; }
                 logStream << "\t(P.hashTable is not written: SAGE2 -m 4 does not need it and sage2ov -m 3 rebuilds the index)\n";
             }
             if (lastStep >= 3) {                                                              // main.cpp:92-132
@@ -122,8 +122,8 @@ int main(int argc, char* argv[]) {
                 OverlapGraph graphObj(&economyObj, &loaderObj);
                 graphObj.convertGraph();
                 logStream << "     Edges in the graph: " << economyObj.stats().edges << "\n\tStep 3 in " << now() - t0 << " sec.\n";
-                if (minStep == 1 && !saveAll) loaderObj.saveReadsInFile(outputDir + prefixName + ".reads");
-                if (lastStep == 3 || saveAll) graphObj.saveOverlapGraphInFile(outputDir + prefixName + ".graph3");      // main.cpp:120-131
+                if (minStep == 1 && !saveAll) { double tw = now(); loaderObj.saveReadsInFile(outputDir + prefixName + ".reads"); logStream << "\t" << prefixName << ".reads written in " << now() - tw << " sec.\n"; }
+                if (lastStep == 3 || saveAll) { double tw = now(); graphObj.saveOverlapGraphInFile(outputDir + prefixName + ".graph3"); logStream << "\t" << prefixName << ".graph3 written in " << now() - tw << " sec.\n"; }      // main.cpp:120-131
                 if (lastStep >= 4) step4(graphObj);
             }
         }

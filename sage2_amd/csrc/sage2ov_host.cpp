@@ -387,17 +387,26 @@ template <class F>
 static int write_formatted(sage2ov_ctx* c, FILE* f, uint64_t n, size_t bytes_per_item, F fmt) {
     const int nt = io_threads(c);
     const uint64_t BATCH = (uint64_t)nt * 262144;                            // bounded memory: tens of MB per thread
-    std::vector<std::string> out(nt);
-    for (uint64_t b0 = 0; b0 < n; b0 += BATCH) {
+    std::vector<std::string> out(nt); std::vector<off_t> at(nt + 1);
+    if (fflush(f) != 0) return c->fail(SAGE2OV_ERR_IO, "write failed");
+    off_t pos = ftello(f); const int fd = fileno(f); bool failed = false;
+    for (uint64_t b0 = 0; b0 < n && !failed; b0 += BATCH) {
         const uint64_t nb = std::min<uint64_t>(BATCH, n - b0);
         #pragma omp parallel num_threads(nt)
         {
             const int t = omp_get_thread_num(); const uint64_t chunk = (nb + nt - 1) / nt, a = b0 + t * chunk, e = std::min(b0 + nb, a + chunk);
             out[t].clear(); if (a < e) out[t].reserve((size_t)(e - a) * bytes_per_item);
             for (uint64_t i = a; i < e; i++) fmt(i, out[t]);
+            #pragma omp barrier
+            #pragma omp single
+            { at[0] = pos; for (int x = 0; x < nt; x++) at[x + 1] = at[x] + (off_t)out[x].size(); }
+            // every thread copies its slice into the page cache at its own offset (one thread doing all the copies was the bottleneck)
+            const char* p = out[t].data(); size_t left = out[t].size(); off_t o = at[t];
+            while (left) { const ssize_t w = pwrite(fd, p, left, o); if (w <= 0) { failed = true; break; } p += w; left -= (size_t)w; o += w; }
         }
-        for (int t = 0; t < nt; t++) if (!out[t].empty() && fwrite(out[t].data(), 1, out[t].size(), f) != out[t].size()) return c->fail(SAGE2OV_ERR_IO, "write failed");
+        pos = at[nt];
     }
+    if (failed || fseeko(f, pos, SEEK_SET) != 0) return c->fail(SAGE2OV_ERR_IO, "write failed");
     return SAGE2OV_OK;
 }
 
@@ -881,17 +890,30 @@ int sage2ov_graph4_save(sage2ov_ctx* c, const char* path) {                     
     FILE* f = fopen(path, "w"); if (!f) return c->fail(SAGE2OV_ERR_IO, std::string("cannot open ") + path);
     std::vector<char> io(1 << 22); setvbuf(f, io.data(), _IOFBF, io.size());
     fprintf(f, "0\n%llu\n%llu\n", (unsigned long long)c->goodReads, (unsigned long long)(c->goodReads ? c->totalBP / c->goodReads : 0));
-    auto rec = [&](uint32_t h, std::string& o) {
-        char buf[96]; char* p = put_u(buf, g.from[h]); *p++ = '\t'; p = put_u(p, g.to[h]); *p++ = '\t'; p = put_u(p, g.type[h]); memcpy(p, "\t1\t", 3); p += 3;
-        p = put_u(p, g.len[h]); memcpy(p, "\t0\t", 3); p += 3; p = put_u(p, g.cnt[h]); *p++ = '\n'; o.append(buf, (size_t)(p - buf));
-        for (uint32_t x = 0; x < g.cnt[h]; x++) {
-            const uint64_t e = g.lists[(uint64_t)g.off[h] + x];
+    // items: a header line, a block of up to 4096 list entries, or the blank line that ends a record -- a contracted chromosome is ONE
+    // edge with millions of entries, so the unit of parallel formatting cannot be the edge
+    struct Item { uint32_t h, first, count; };                                          // count == 0: header; first == ~0u: blank line
+    std::vector<Item> items; items.reserve(order.size() * 4);
+    for (uint32_t h0 : order)
+        for (uint32_t h : {h0, h0 ^ 1u}) {
+            items.push_back(Item{h, 0, 0});
+            for (uint32_t x = 0; x < g.cnt[h]; x += 4096) items.push_back(Item{h, x, std::min<uint32_t>(4096, g.cnt[h] - x)});
+            items.push_back(Item{h, ~0u, 1});
+        }
+    int rc = write_formatted(c, f, items.size(), 64, [&](uint64_t x, std::string& o) {
+        const Item it = items[x]; const uint32_t h = it.h; char buf[96]; char* p;
+        if (it.first == ~0u) { o.push_back('\n'); return; }
+        if (it.count == 0) {
+            p = put_u(buf, g.from[h]); *p++ = '\t'; p = put_u(p, g.to[h]); *p++ = '\t'; p = put_u(p, g.type[h]); memcpy(p, "\t1\t", 3); p += 3;
+            p = put_u(p, g.len[h]); memcpy(p, "\t0\t", 3); p += 3; p = put_u(p, g.cnt[h]); *p++ = '\n'; o.append(buf, (size_t)(p - buf));
+            return;
+        }
+        for (uint32_t y = it.first; y < it.first + it.count; y++) {
+            const uint64_t e = g.lists[(uint64_t)g.off[h] + y];
             p = put_u(buf, (unsigned long long)(e & ((1ull << 40) - 1))); *p++ = '\t'; *p++ = (char)('0' + ((e >> 40) & 1)); *p++ = '\t'; *p++ = (char)('0' + ((e >> 41) & 1)); *p++ = '\t';
             p = put_u(p, (unsigned)((e >> 42) & 0x7FF)); *p++ = '\t'; p = put_u(p, (unsigned)((e >> 53) & 0x7FF)); *p++ = '\n'; o.append(buf, (size_t)(p - buf));
         }
-        o.push_back('\n');
-    };
-    int rc = write_formatted(c, f, order.size(), 96, [&](uint64_t x, std::string& o) { const uint32_t h = order[x]; rec(h, o); rec(h ^ 1u, o); });
+    });
     fclose(f); return rc;
 }
 

@@ -12,4 +12,4 @@ t0 = time.time()
 subprocess.run([os.path.join(R, "sage2_amd", "sage2ov"), "-f", fa, "-k", "40", "-o", out, "-p", "t", "-M", max_step], check=True)
 print("CLI total: %.2f s" % (time.time() - t0))
 log = open(os.path.join(out, "t.log")).read()
-print("\n".join(l for l in log.splitlines() if "ime" in l or "sec" in l)[:1500])
+print("\n".join(l for l in log.splitlines() if "ime" in l or "sec" in l or "written" in l)[:1500])
