@@ -1,5 +1,5 @@
 /* ============================================================================
- * sage2ov.h -- C ABI of the MI355X-native SAGE2 read-overlap path (CLI steps 1-3).
+ * sage2ov.h -- C ABI of the MI355X-native SAGE2 read-overlap path (CLI steps 1-3; step 4 at the end of the file).
  *
  * SAGE2 has no plugin/FFI interface; its replaceable seam is (a) the step/prefix file
  * API (<outdir>/<prefix>.reads + <prefix>.graph3, consumed by `SAGE2 -m 4 -i <prefix>`,

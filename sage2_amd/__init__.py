@@ -1,4 +1,4 @@
-"""sage2_amd -- ctypes binding of libsage2ov.so, the MI355X-native SAGE2 read-overlap path (steps 1-3).
+"""sage2_amd -- ctypes binding of libsage2ov.so, the MI355X-native SAGE2 read-overlap path (steps 1-3, and the graph simplification of step 4).
 
 The product is the C-ABI library (include/sage2ov.h) built from sage2_amd/csrc by __graft_entry__.build()
 or `make -C sage2_amd/csrc`.  This module only loads it and wraps the calls; it never computes anything
