@@ -878,7 +878,7 @@ int dev_simplify(Device* d, SimplifiedGraph& out, std::string& err) {
                 fin = a;
             }
             HIPCHK(hipMemsetAsync(tab, 0xFF, sizeof(S4Pair) << tabBits, st)); HIPCHK(hipMemsetAsync(dctr, 0, 8 * sizeof(u32), st));
-            hipLaunchKernelGGL(k_s4_chain, gN, b256, 0, st, g, N, cont, fin, role, tab, tabMask, dctr);
+            hipLaunchKernelGGL(k_s4_chain, gN, b256, 0, st, g, N, cont, fin, stA, role, tab, tabMask, dctr);
             hipLaunchKernelGGL(k_s4_parallel, gN, b256, 0, st, g, N, fin, role, tab, tabMask, dctr);
             u32 pz[2] = {0, 0}; if (rd(pz, 2)) { err = "step 4: counter read failed"; return SAGE2OV_ERR_DEVICE; }
             if (pz[1]) { if (plainJumping) { err = "step 4: chain states left unwritten"; return SAGE2OV_ERR_INTERNAL; } plainJumping = true; round--; continue; }   // a cycle without a splitter
