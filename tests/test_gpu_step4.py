@@ -197,3 +197,35 @@ def test_hub_with_thousands_of_edges(tmp_path):
     for i, (a, b, t, ln) in enumerate(rows):
         e[i]["from"], e[i]["to"], e[i]["type"], e[i]["length"], e[i]["length_twin"] = a, b, t, ln, ln
     _run_imported(N, e, tmp_path, "hub")
+
+
+def test_full_size_properties_c2(tmp_path):
+    """BASELINE configs[1] at full size, step 4: the reduced graph of an error-free chromosome is one path, so the sweep contracts every
+    read but the two ends into ONE edge pair; size-independent properties of the written file: both read lists hold every contracted
+    read exactly once, the twin's list is the forward list reversed with the orientations flipped, distances mirror, the edge lengths
+    are the sums of the steps; a second run gives the same bytes."""
+    import zlib
+    pd = dict(seed=2, genome_len=30_000_000, n_reads=10_000_000, read_len=150)
+    p = fx.synth_params(pd)
+    ctx = s2.Context(40, device=0)
+    ctx.reads_add_synth(p, s2.synth_genome(p)); ctx.reads_organize(); ctx.run_steps23()
+    n = ctx.reads_stats().unique_reads
+    ctx.graph_simplify(); st = ctx.simplify_stats()
+    assert (st.nodes_contracted, st.removed, st.edges, st.reads_on_edges) == (n - 2, 0, 1, n - 2)
+    out = str(tmp_path / "t.graph4"); ctx.graph4_save(out)
+    raw = open(out, "rb").read(); crc = zlib.crc32(raw)
+    lines = raw.split(b"\n")
+    hdr = lines[3].split(b"\t"); a, b, cnt = int(hdr[0]), int(hdr[1]), int(hdr[6])
+    assert cnt == n - 2 and a < b
+    fwd = np.loadtxt(lines[4:4 + cnt], dtype=np.int64).reshape(cnt, 5)
+    k2 = 4 + cnt + 1                                             # blank line, then the twin
+    hdr2 = lines[k2].split(b"\t"); assert (int(hdr2[0]), int(hdr2[1]), int(hdr2[6])) == (b, a, cnt)
+    rev = np.loadtxt(lines[k2 + 1:k2 + 1 + cnt], dtype=np.int64).reshape(cnt, 5)
+    ids = np.sort(fwd[:, 0]); assert np.array_equal(ids, np.setdiff1d(np.arange(1, n + 1), [a, b]))
+    assert np.array_equal(rev[::-1, 0], fwd[:, 0]) and np.array_equal(rev[::-1, 1], 1 - fwd[:, 1])
+    assert np.array_equal(rev[::-1, 3], fwd[:, 4]) and np.array_equal(rev[::-1, 4], fwd[:, 3])          # equal read lengths: a step has one length both ways
+    assert np.array_equal(fwd[1:, 3], fwd[:-1, 4])                                                      # distPrevious of a read = distNext of the one before
+    assert int(hdr[4]) == int(fwd[:, 3].sum() + fwd[-1, 4]) and int(hdr2[4]) == int(hdr[4])
+    ctx.graph_simplify(); out2 = str(tmp_path / "u.graph4"); ctx.graph4_save(out2)
+    assert zlib.crc32(open(out2, "rb").read()) == crc
+    ctx.close()
