@@ -91,6 +91,19 @@ def cpu_baseline(args, s2, fx):
             out = dict(value=nov / T, unit="overlaps/s", cores=threads, kind="reference", sample=sample,
                        seconds=dict(index=t[2], initial=t[3], reduce=t[4], sort_convert=t[5]),
                        graph3_identical_to_gpu=bool(same))
+            # the same path on ONE thread, on a quarter of the sample at the same coverage, and all threads on that same
+            # quarter beside it: the reference's cost per overlap grows with the size of its table, so only equal samples compare
+            n1 = max(20000, n // 4)
+            pd1 = dict(seed=args.seed + 2000, genome_len=int(n1 * args.read_len / cov), n_reads=n1, read_len=args.read_len)
+            fa1 = os.path.join(tmp, "sample1.fa"); s2.synth_write_fasta(fx.synth_params(pd1), fa1)
+            c1 = s2.Context(args.k, device=0); c1.reads_add_file(fa1); c1.reads_organize(); c1.run_steps23(); nov1 = c1.overlap_stats().verified_overlaps; c1.close()
+            t1 = (C.c_double * 6)(); cc1 = (C.c_ulonglong * 3)()
+            if L.sage2ref_run_steps123(fa1.encode(), args.k, 1, None, t1, cc1) == 0:
+                T1 = t1[2] + t1[3] + t1[4] + t1[5]
+                out["one_thread"] = dict(value=nov1 / T1, unit="overlaps/s", cores=1, sample=f"{n1} x {args.read_len} bp reads, same coverage", seconds=T1)
+                if L.sage2ref_run_steps123(fa1.encode(), args.k, threads, None, t1, cc1) == 0:
+                    Tn = t1[2] + t1[3] + t1[4] + t1[5]
+                    out["one_thread"]["all_threads_same_sample"] = dict(value=nov1 / Tn, cores=threads, seconds=Tn)
             if hasattr(L, "sage2ref_run_step4") and ours4:
                 # step 4 of the reference on the same sample (its loaders, its loop, its writer), against our P.graph4
                 t4 = (C.c_double * 2)(); c4 = (C.c_ulonglong * 4)()
