@@ -33,7 +33,7 @@ typedef unsigned long long u64;
 typedef unsigned int u32;
 
 enum { WS_SLOTS, WS_CNT, WS_WHERE, WS_BIG, WS_CSR, WS_SLOW, WS_NEED, WS_DEG, WS_OFFS, WS_CURSOR, WS_KEYS, WS_KEEP, WS_POS, WS_OWNER, WS_FINAL,
-       WS_PARTIAL, WS_IDS, WS_NEAR, WS_HITS, WS_MINH, WS_OCNT, WS_OOFF, WS_OCUR, WS_ORDER, WS_MI1, WS_MICNT, WS_MICUR, WS_KREC, WS_SLOTMH, WS_RA_DEG, WS_RA_OFF, WS_RA_CUR, WS_RA_ENT, WS_RA_RM, WS_ORG_POOL, WS_ORG_OFF, WS_ORG_LEN, WS_ORG_IMG, WS_ORG_K0, WS_ORG_K1, WS_ORG_V0, WS_ORG_V1, WS_ORG_HIST, WS_ORG_HSCAN, WS_ORG_FLAG, WS_ORG_UID, WS_ORG_HEAD, WS_COUNT };   // ids of the workspace arena (Device::ws)
+       WS_PARTIAL, WS_IDS, WS_NEAR, WS_HITS, WS_MINH, WS_OCNT, WS_OOFF, WS_OCUR, WS_ORDER, WS_MI1, WS_MICNT, WS_MICUR, WS_KREC, WS_SLOTMH, WS_RA_DEG, WS_RA_OFF, WS_RA_CUR, WS_RA_ENT, WS_RA_RM, WS_ORG_POOL, WS_ORG_OFF, WS_ORG_LEN, WS_ORG_IMG, WS_ORG_K0, WS_ORG_K1, WS_ORG_V0, WS_ORG_V1, WS_ORG_HIST, WS_ORG_HSCAN, WS_ORG_FLAG, WS_ORG_UID, WS_ORG_HEAD, WS_RR_IN, WS_RR_DEGP, WS_RR_OFFP, WS_RR_ENTP, WS_RR_OUTP, WS_RR_WIDX, WS_RR_RANK, WS_RR_CUR, WS_COUNT };   // ids of the workspace arena (Device::ws)
 struct Device {
     int ordinal = 0;
     hipStream_t stream = nullptr;
@@ -547,6 +547,48 @@ int dev_unresolved_hits(Device* d, std::vector<Hit>& hits, uint64_t* n_unresolve
 // Reduce phase on the device (see k_ra_mark).  *done = 0 when the preconditions do not hold (long buckets, too few
 // unresolved reads to be worth it, a list longer than RA_CAP, 32-bit offsets exhausted): the caller then runs the
 // serial replay on the host; nothing but the idempotent 0x80 flags has been changed in that case.
+// The serial part of the reduce phase when some bucket is long (economyGraph.cpp:513-564): the order in which the unresolved reads are
+// explored.  plist[offp[w] .. offp[w+1]) = potential list of the w-th unresolved read, sorted like the reference sorts a list when the
+// read is explored (:853-871); an entry is `to | twin << 31`.  An own hit is in the read's list iff the target was still unexplored
+// when the read was explored, a twin iff its source had been explored before; candidates of the reciprocal pass (hasCand) are always
+// there but their far ends are never explorable.  Returns rank[id] (1-based exploration order; 0: not an unresolved read).
+static void explore_order(const std::vector<u32>& ids, const std::vector<u32>& offp, const std::vector<u32>& plist, const std::vector<uint8_t>& hasCand,
+                          u64 N, std::vector<u32>& rank) {
+    const size_t n = ids.size();
+    std::vector<u32> widx(N + 2, 0); for (size_t w = 0; w < n; w++) widx[ids[w]] = (u32)w + 1;
+    rank.assign(N + 2, 0);                                                       // by read id: 0 = unexplored (status 0), else 1-based exploration order
+    std::vector<uint8_t> marked(N + 2, 0);                                       // status 2 (:679)
+    u32 ctr = 0;
+    // one look-up per entry: an own hit is in the list iff its target was explored later (or not yet), a twin iff its source was explored earlier
+    auto present = [&](u32 rw, u32 e) -> bool { const u32 to = e & 0x7FFFFFFFu, rt = rank[to]; return (e >> 31) ? (rt != 0 && rt < rw) : (to != 0 && (rt == 0 || rt > rw)); };
+    std::vector<u32> order(ids.begin(), ids.end()); std::sort(order.begin(), order.end());
+    std::vector<u32> queue;
+    auto explore_neighbours = [&](u32 w) {                                       // every still unexplored neighbour, in list order (:531-541)
+        for (u32 x = offp[w]; x < offp[w + 1]; x++) {
+            const u32 e = plist[x]; if (e >> 31 || e == 0) continue;
+            if (rank[e] == 0) { rank[e] = ++ctr; queue.push_back(e); }
+        }
+    };
+    for (u32 id0 : order) {
+        if (rank[id0] != 0) continue;
+        queue.clear(); size_t start = 0; queue.push_back(id0);
+        while (start < queue.size()) {
+            const u32 r1 = queue[start++], w1 = widx[r1] - 1;
+            if (rank[r1] == 0) rank[r1] = ++ctr;
+            const u32 rw = rank[r1];
+            bool any = hasCand[w1] != 0;
+            for (u32 x = offp[w1]; !any && x < offp[w1 + 1]; x++) any = present(rw, plist[x]);
+            if (!any) continue;                                                  // an empty list (:527)
+            if (!marked[r1]) { explore_neighbours(w1); marked[r1] = 1; }
+            for (u32 x = offp[w1]; x < offp[w1 + 1]; x++) {                      // (:543-561) neighbours that are explored but not yet marked
+                const u32 e = plist[x]; if (!present(rw, e)) continue;
+                const u32 r2 = e & 0x7FFFFFFFu; if (rank[r2] == 0 || marked[r2]) continue;
+                explore_neighbours(widx[r2] - 1); marked[r2] = 1;
+            }
+        }
+    }
+}
+
 int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved, uint64_t* n_hits, uint64_t* inserted, uint64_t* removed, int* done, std::string& err) {
     HIPCHK(hipSetDevice(d->ordinal));
     *done = 0; *inserted = 0; *removed = 0; *n_hits = 0;
@@ -567,7 +609,8 @@ int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved
     }
     *n_unresolved = nun;
     if (nun == 0) { *done = 1; return 0; }
-    if (d->n_long != 0 || nun < min_unresolved) return 0;
+    if (nun < min_unresolved) return 0;
+    const bool ranked = d->n_long != 0;                                          // one-sided discovery: the exploration order decides which edges exist
     // directional hits of the unresolved reads, device resident: the fast kernel in its hit-list form (locality order, minimiser
     // groups), the sequential kernel for the few reads it hands over (> 128 candidates, ambiguous tags) and for the 16-word layout
     Hit* dh = nullptr; u64 nh = 0, nslots = 0;
@@ -609,12 +652,40 @@ int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved
     WS(deg, u32, WS_RA_DEG, N + 2); WS(offs, u32, WS_RA_OFF, N + 2); WS(cur, u32, WS_CURSOR, N + 2);
     HIPCHK(hipMemsetAsync(deg, 0, (N + 2) * sizeof(u32), d->stream)); HIPCHK(hipMemsetAsync(cur, 0, (N + 2) * sizeof(u32), d->stream));
     if (nc) hipLaunchKernelGGL(k_ra_degree_c, dim3(grid_for(nc, 256)), dim3(256), 0, d->stream, d->cand, (u64)nc, d->status, deg);
-    hipLaunchKernelGGL(k_ra_degree_h, dim3(grid_for(N + 1, 256)), dim3(256), 0, d->stream, hitcount, (u64)N, deg);
+    u32* rankDev = nullptr; u64 present = 0;
+    HIPCHK(hipMemsetAsync(d->d_counters + 8, 0, 4 * sizeof(u64), d->stream));
+    if (ranked) {
+        // potential lists (own hits + twins of incoming hits), sorted on the device; exploration order on the host; ranks back
+        WS(incount, u32, WS_RR_IN, N + 2); WS(widx, u32, WS_RR_WIDX, N + 2); WS(degp, u32, WS_RR_DEGP, nun + 2); WS(offp, u32, WS_RR_OFFP, nun + 2); WS(pcur, u32, WS_RR_CUR, N + 2);
+        HIPCHK(hipMemsetAsync(incount, 0, (N + 2) * sizeof(u32), d->stream)); HIPCHK(hipMemsetAsync(pcur, 0, (N + 2) * sizeof(u32), d->stream));
+        hipLaunchKernelGGL(k_rr_widx, dim3(grid_for(nun, 256)), dim3(256), 0, d->stream, ids, (u64)nun, widx);
+        if (nslots) hipLaunchKernelGGL(k_rr_incount, dim3(grid_for(nslots, 256)), dim3(256), 0, d->stream, dh, (u64)nslots, incount);
+        hipLaunchKernelGGL(k_rr_degp, dim3(grid_for(nun, 256)), dim3(256), 0, d->stream, ids, (u64)nun, hitcount, incount, degp);
+        u64 totp = 0; { int rc = scan_u32(d, degp, nun, offp, &totp, err); if (rc) return rc; }
+        if (totp >= (1ull << 32) - 64) return 0;
+        WS(entp, u64, WS_RR_ENTP, totp + 64); WS(outp, u32, WS_RR_OUTP, totp + 64);
+        HIPCHK(hipMemsetAsync(entp, 0, (totp + 64) * sizeof(u64), d->stream));
+        if (nslots) hipLaunchKernelGGL(k_rr_fillp, dim3(grid_for(nslots, 256)), dim3(256), 0, d->stream, dh, (u64)nslots, d->reads, d->S, d->uniL, widx, offp, hitcount, pcur, entp);
+        hipLaunchKernelGGL(k_rr_sortp, dim3((unsigned)std::min<u64>((nun + 3) / 4, 256ull * 16)), dim3(256), 0, d->stream, (u64)nun, offp, degp, entp, outp, d->d_counters + 8 + 3);
+        u64 over = 0; HIPCHK(hipMemcpyAsync(&over, d->d_counters + 8 + 3, sizeof over, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
+        if (over) return 0;                                                       // a list beyond the device sort: serial replay
+        std::vector<u32> hIds(nun), hOff(nun + 1), hP(totp), hDeg(N + 2); std::vector<uint8_t> hasCand(nun, 0);
+        HIPCHK(hipMemcpy(hIds.data(), ids, nun * sizeof(u32), hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(hOff.data(), offp, nun * sizeof(u32), hipMemcpyDeviceToHost)); hOff[nun] = (u32)totp;
+        if (totp) HIPCHK(hipMemcpy(hP.data(), outp, totp * sizeof(u32), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(hDeg.data(), deg, (N + 2) * sizeof(u32), hipMemcpyDeviceToHost));     // so far: candidate entries only
+        for (u64 w = 0; w < nun; w++) hasCand[w] = hDeg[hIds[w]] != 0;
+        std::vector<u32> rankById; explore_order(hIds, hOff, hP, hasCand, N, rankById);
+        { WS(rk, u32, WS_RR_RANK, N + 2); rankDev = rk; }
+        HIPCHK(hipMemcpy(rankDev, rankById.data(), (N + 2) * sizeof(u32), hipMemcpyHostToDevice));
+        if (nslots) hipLaunchKernelGGL(k_rr_degree_h, dim3(grid_for(nslots, 256)), dim3(256), 0, d->stream, dh, (u64)nslots, rankDev, deg, d->d_counters + 8);
+    } else hipLaunchKernelGGL(k_ra_degree_h, dim3(grid_for(N + 1, 256)), dim3(256), 0, d->stream, hitcount, (u64)N, deg);
     u64 tot = 0; { int rc = scan_u32(d, deg, N + 2, offs, &tot, err); if (rc) return rc; }
     if (tot >= (1ull << 32) - 64) return 0;
     WS(ent, u64, WS_RA_ENT, tot + 64); WS(rm, uint8_t, WS_RA_RM, tot + 64);
     if (nc) hipLaunchKernelGGL(k_ra_fill_c, dim3(grid_for(nc, 256)), dim3(256), 0, d->stream, d->cand, (u64)nc, d->reads, d->S, d->uniL, offs, cur, ent);
-    if (nslots) hipLaunchKernelGGL(k_ra_fill_h, dim3(grid_for(nslots, 256)), dim3(256), 0, d->stream, dh, (u64)nslots, offs, deg, hitcount, ent);
+    if (ranked) { if (nslots) hipLaunchKernelGGL(k_rr_fill_h, dim3(grid_for(nslots, 256)), dim3(256), 0, d->stream, dh, (u64)nslots, rankDev, d->reads, d->S, d->uniL, offs, cur, ent); }
+    else if (nslots) hipLaunchKernelGGL(k_ra_fill_h, dim3(grid_for(nslots, 256)), dim3(256), 0, d->stream, dh, (u64)nslots, offs, deg, hitcount, ent);
+    if (ranked) { u64 c3[3]; HIPCHK(hipMemcpyAsync(c3, d->d_counters + 8, sizeof c3, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream)); present = c3[2]; }
     HIPCHK(hipMemsetAsync(d->d_counters + 8, 0, 4 * sizeof(u64), d->stream));
     WS(svn, u32, WS_NEED, nun + 2); WS(svoff, u32, WS_OWNER, nun + 2);
     const unsigned gb = (unsigned)std::min<u64>((nun + 3) / 4, 256ull * 16);
@@ -633,7 +704,7 @@ int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved
     hipLaunchKernelGGL(k_ra_emit, dim3(gb), dim3(256), 0, d->stream, ids, (u64)nun, offs, deg, ent, rm, svoff, d->cand, (u64)d->n_cand, (u64)d->cand_cap);
     HIPCHK(hipGetLastError());
     d->n_cand += nsv;
-    *inserted = nh; *removed = c[1]; *done = 1;
+    *inserted = ranked ? 2 * present : nh; *removed = c[1]; *done = 1;
     HIPCHK(hipEventRecord(d->ev[1], d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
     float ms = 0; hipEventElapsedTime(&ms, d->ev[0], d->ev[1]); d->tm.hits_ms += ms;
     return 0;

@@ -337,7 +337,10 @@ struct Replay {
         a.erase(std::remove_if(a.begin(), a.end(), [](const AdjEdge& e) { return e.mark != 0; }), a.end());
         return before - a.size();
     }
+    bool timing = false;
     void run(const std::vector<uint32_t>& ids) {
+        auto tp = std::chrono::steady_clock::now();
+        auto lap = [&](const char* what) { if (!timing) return; auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[reduce/host]   %-26s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(t - tp).count()); tp = t; };
         std::vector<uint32_t> queue;
         for (uint32_t i : ids) {                                                     // the serial part: exploration order (:513-564)
             if (status_id(i) != 0) continue;
@@ -361,6 +364,7 @@ struct Replay {
                 }
             }
         }
+        lap("serial exploration");
         // marks on the final lists (all reads first: they read their neighbours' unreduced lists), then the removals (:681-707)
         const int64_t n = (int64_t)ids.size();
         const int nthr = io_threads(c);
@@ -370,10 +374,12 @@ struct Replay {
             #pragma omp for schedule(dynamic, 1024)
             for (int64_t x = 0; x < n; x++) { const uint32_t d = dense[ids[x]] - 1; if (st[d] == 2 && !adj[d].empty()) mark_edges(ids[x], mkb); }
         }
+        lap("marks (parallel)");
         uint64_t rem = 0;
         #pragma omp parallel for num_threads(nthr) schedule(dynamic, 1024) reduction(+ : rem) if (n > 4096)
         for (int64_t x = 0; x < n; x++) { const uint32_t d = dense[ids[x]] - 1; if (st[d] == 2) rem += remove_marked(ids[x]); }
         removed += rem;
+        lap("removals (parallel)");
     }
 };
 
@@ -733,12 +739,17 @@ int sage2ov_overlap_reduce(sage2ov_ctx* c) {
         }
     }
     std::vector<Hit> hits; uint64_t nun = 0;
+    const bool timing = getenv("SAGE2OV_TIMING") != nullptr; auto tp = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) { if (!timing) return; auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[reduce/host] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(t - tp).count()); tp = t; };
     int rc = dev_unresolved_hits(c->dev, hits, &nun, c->err); if (rc) return rc;
+    lap("hit lists (device + download)");
     c->ostats.unresolved_hits = hits.size(); c->ostats.edges_inserted = 0; c->ostats.transitive_removed = 0;
     if (nun) {
         std::vector<uint32_t> ids; rc = dev_unresolved_ids(c->dev, ids, c->err); if (rc) return rc;
         std::vector<EdgeCand> near; rc = dev_collect_reduce_edges(c->dev, near, c->err); if (rc) return rc;
+        lap("ids + nearby candidates");
         __gnu_parallel::sort(hits.begin(), hits.end(), [](const Hit& a, const Hit& b) { return a.from != b.from ? a.from < b.from : a.seq < b.seq; });
+        lap("sort hits");
         if (c->replayDense.size() != c->N + 2) c->replayDense.assign(c->N + 2, 0);
         Replay R(c->replayDense); R.c = c; R.hits = &hits;
         for (uint32_t i : ids) R.add(i);
@@ -754,12 +765,15 @@ int sage2ov_overlap_reduce(sage2ov_ctx* c) {
             const int d2 = (int)c->len[e.from] - ((int)c->len[e.to] - (int)e.len);
             R.adj[R.dense[e.to] - 1].push_back(AdjEdge{e.from, (uint8_t)flip_type_host(e.type), 0, (uint32_t)d2 & 0xFFFFFu});
         }
-        R.run(ids);
+        lap("replay set-up");
+        R.timing = timing; R.run(ids);
+        lap("replay (total)");
         c->ostats.edges_inserted = R.inserted; c->ostats.transitive_removed = R.removed;
         // surviving list entries of unresolved reads with to > from replace what the device dropped
         std::vector<EdgeCand> survivors;
         for (uint32_t i : ids) for (auto& e : R.adj[R.dense[i] - 1]) if (e.to > i) survivors.push_back(EdgeCand{i, e.to, e.len, e.type});
         rc = dev_append_edges(c->dev, survivors.data(), survivors.size(), c->err); if (rc) return rc;
+        lap("survivors -> device");
     }
     c->reduce_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     c->reduced = true; c->converted = false; return SAGE2OV_OK;

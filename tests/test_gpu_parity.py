@@ -570,3 +570,22 @@ def test_device_organizer_full_sort_path_equals_default(monkeypatch):
         out[mode] = g.reads_export(); g.close()
     for a, b in zip(out["default"], out["full"]):
         assert np.array_equal(a, b)
+
+
+def test_long_bucket_reduce_ranked_device_path_equals_serial_replay(monkeypatch):
+    """high-copy repeats (long buckets: one-sided discovery) with read errors, 300 k reads: the default path (exploration order on the
+    host, lists / marks / removals on the device) against the serial replay of the whole phase on the host -- same edges, same counters"""
+    pd = dict(seed=31, genome_len=900000, n_reads=300000, read_len=150, err_ppm=1500, n_repeat_families=5, repeat_copies=250, repeat_len=350)
+    bases, off = fx.make_reads(pd)
+    res = {}
+    for mode in ("default", "host"):
+        if mode == "host":
+            monkeypatch.setenv("SAGE2OV_HOST_REDUCE", "1")
+        else:
+            monkeypatch.delenv("SAGE2OV_HOST_REDUCE", raising=False)
+        ctx = s2.Context(40); ctx.reads_add_ascii(bases, off); ctx.reads_organize(); ctx.run_steps23()
+        st = ctx.overlap_stats(); res[mode] = (ctx.edges().tobytes(), st.edges_inserted, st.transitive_removed, st.left_to_explore, ctx.index_stats().long_buckets)
+        ctx.close()
+    assert res["default"][4] > 0 and res["default"][3] > 100000
+    assert res["default"][1:] == res["host"][1:]
+    assert res["default"][0] == res["host"][0]
