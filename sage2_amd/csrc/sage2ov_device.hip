@@ -12,6 +12,7 @@
 #include <cstring>
 #include <cstdlib>
 #include <vector>
+#include <chrono>
 #include <memory>
 #include "sage2ov.h"
 #include "sage2ov_internal.h"
@@ -611,6 +612,8 @@ int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved
     if (nun == 0) { *done = 1; return 0; }
     if (nun < min_unresolved) return 0;
     const bool ranked = d->n_long != 0;                                          // one-sided discovery: the exploration order decides which edges exist
+    const bool timing = getenv("SAGE2OV_TIMING") != nullptr; auto tp = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) { if (!timing) return; hipStreamSynchronize(d->stream); auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[reduce/device] %-30s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(t - tp).count()); tp = t; };
     // directional hits of the unresolved reads, device resident: the fast kernel in its hit-list form (locality order, minimiser
     // groups), the sequential kernel for the few reads it hands over (> 128 candidates, ambiguous tags) and for the 16-word layout
     Hit* dh = nullptr; u64 nh = 0, nslots = 0;
@@ -648,6 +651,7 @@ int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved
         if (!ok) { err = "hit buffer sizing failed"; return SAGE2OV_ERR_INTERNAL; }
     }
     *n_hits = nh;
+    lap("hit lists");
     const u64 nc = d->n_cand;
     WS(deg, u32, WS_RA_DEG, N + 2); WS(offs, u32, WS_RA_OFF, N + 2); WS(cur, u32, WS_CURSOR, N + 2);
     HIPCHK(hipMemsetAsync(deg, 0, (N + 2) * sizeof(u32), d->stream)); HIPCHK(hipMemsetAsync(cur, 0, (N + 2) * sizeof(u32), d->stream));
@@ -668,13 +672,16 @@ int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved
         if (nslots) hipLaunchKernelGGL(k_rr_fillp, dim3(grid_for(nslots, 256)), dim3(256), 0, d->stream, dh, (u64)nslots, d->reads, d->S, d->uniL, widx, offp, hitcount, pcur, entp);
         hipLaunchKernelGGL(k_rr_sortp, dim3((unsigned)std::min<u64>((nun + 3) / 4, 256ull * 16)), dim3(256), 0, d->stream, (u64)nun, offp, degp, entp, outp, d->d_counters + 8 + 3);
         u64 over = 0; HIPCHK(hipMemcpyAsync(&over, d->d_counters + 8 + 3, sizeof over, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
+        lap("potential lists (build + sort)");
         if (over) return 0;                                                       // a list beyond the device sort: serial replay
         std::vector<u32> hIds(nun), hOff(nun + 1), hP(totp), hDeg(N + 2); std::vector<uint8_t> hasCand(nun, 0);
         HIPCHK(hipMemcpy(hIds.data(), ids, nun * sizeof(u32), hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(hOff.data(), offp, nun * sizeof(u32), hipMemcpyDeviceToHost)); hOff[nun] = (u32)totp;
         if (totp) HIPCHK(hipMemcpy(hP.data(), outp, totp * sizeof(u32), hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(hDeg.data(), deg, (N + 2) * sizeof(u32), hipMemcpyDeviceToHost));     // so far: candidate entries only
         for (u64 w = 0; w < nun; w++) hasCand[w] = hDeg[hIds[w]] != 0;
+        lap("potential lists -> host");
         std::vector<u32> rankById; explore_order(hIds, hOff, hP, hasCand, N, rankById);
+        lap("exploration order (host)");
         { WS(rk, u32, WS_RR_RANK, N + 2); rankDev = rk; }
         HIPCHK(hipMemcpy(rankDev, rankById.data(), (N + 2) * sizeof(u32), hipMemcpyHostToDevice));
         if (nslots) hipLaunchKernelGGL(k_rr_degree_h, dim3(grid_for(nslots, 256)), dim3(256), 0, d->stream, dh, (u64)nslots, rankDev, deg, d->d_counters + 8);
@@ -701,6 +708,7 @@ int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved
         HIPCHK(hipMemcpyAsync(ncand, d->cand, d->n_cand * sizeof(EdgeCand), hipMemcpyDeviceToDevice, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
         hipFree(d->cand); d->cand = ncand; d->cand_cap = ncap;
     }
+    lap("final lists + marks");
     hipLaunchKernelGGL(k_ra_emit, dim3(gb), dim3(256), 0, d->stream, ids, (u64)nun, offs, deg, ent, rm, svoff, d->cand, (u64)d->n_cand, (u64)d->cand_cap);
     HIPCHK(hipGetLastError());
     d->n_cand += nsv;
