@@ -553,21 +553,22 @@ int dev_unresolved_hits(Device* d, std::vector<Hit>& hits, uint64_t* n_unresolve
 // read is explored (:853-871); an entry is `to | twin << 31`.  An own hit is in the read's list iff the target was still unexplored
 // when the read was explored, a twin iff its source had been explored before; candidates of the reciprocal pass (hasCand) are always
 // there but their far ends are never explorable.  Returns rank[id] (1-based exploration order; 0: not an unresolved read).
-static void explore_order(const std::vector<u32>& ids, const std::vector<u32>& offp, const std::vector<u32>& plist, const std::vector<uint8_t>& hasCand,
+static void explore_order(const std::vector<u32>& ids, const std::vector<u32>& offp, const std::vector<u32>& lenp, const std::vector<u32>& plist, const std::vector<uint8_t>& hasCand,
                           u64 N, std::vector<u32>& rank) {
     const size_t n = ids.size();
     std::vector<u32> widx(N + 2, 0); for (size_t w = 0; w < n; w++) widx[ids[w]] = (u32)w + 1;
     rank.assign(N + 2, 0);                                                       // by read id: 0 = unexplored (status 0), else 1-based exploration order
     std::vector<uint8_t> marked(N + 2, 0);                                       // status 2 (:679)
     u32 ctr = 0;
-    // one look-up per entry: an own hit is in the list iff its target was explored later (or not yet), a twin iff its source was explored earlier
-    auto present = [&](u32 rw, u32 e) -> bool { const u32 to = e & 0x7FFFFFFFu, rt = rank[to]; return (e >> 31) ? (rt != 0 && rt < rw) : (to != 0 && (rt == 0 || rt > rw)); };
+    constexpr u32 IDM = 0x3FFFFFFFu;                                             // entry = to | kind << 30: 0 both sides see each other, 1 own hit only, 2 twin only
+    // one look-up per entry: an own-only hit is in the list iff its target was explored later (or not yet), a twin-only one iff its source was explored earlier
+    auto present = [&](u32 rw, u32 e) -> bool { const u32 k = e >> 30; if (k == 0) return true; const u32 rt = rank[e & IDM]; return k == 1 ? (rt == 0 || rt > rw) : (rt != 0 && rt < rw); };
     std::vector<u32> order(ids.begin(), ids.end()); std::sort(order.begin(), order.end());
     std::vector<u32> queue;
-    auto explore_neighbours = [&](u32 w) {                                       // every still unexplored neighbour, in list order (:531-541)
-        for (u32 x = offp[w]; x < offp[w + 1]; x++) {
-            const u32 e = plist[x]; if (e >> 31 || e == 0) continue;
-            if (rank[e] == 0) { rank[e] = ++ctr; queue.push_back(e); }
+    auto explore_neighbours = [&](u32 w) {                                       // every still unexplored neighbour this read sees, in list order (:531-541)
+        for (u32 x = offp[w], en = offp[w] + lenp[w]; x < en; x++) {
+            const u32 e = plist[x]; if ((e >> 30) == 2) continue;
+            const u32 to = e & IDM; if (rank[to] == 0) { rank[to] = ++ctr; queue.push_back(to); }
         }
     };
     for (u32 id0 : order) {
@@ -576,14 +577,14 @@ static void explore_order(const std::vector<u32>& ids, const std::vector<u32>& o
         while (start < queue.size()) {
             const u32 r1 = queue[start++], w1 = widx[r1] - 1;
             if (rank[r1] == 0) rank[r1] = ++ctr;
-            const u32 rw = rank[r1];
+            const u32 rw = rank[r1], b1 = offp[w1], e1 = offp[w1] + lenp[w1];
             bool any = hasCand[w1] != 0;
-            for (u32 x = offp[w1]; !any && x < offp[w1 + 1]; x++) any = present(rw, plist[x]);
+            for (u32 x = b1; !any && x < e1; x++) any = present(rw, plist[x]);
             if (!any) continue;                                                  // an empty list (:527)
             if (!marked[r1]) { explore_neighbours(w1); marked[r1] = 1; }
-            for (u32 x = offp[w1]; x < offp[w1 + 1]; x++) {                      // (:543-561) neighbours that are explored but not yet marked
+            for (u32 x = b1; x < e1; x++) {                                      // (:543-561) neighbours that are explored but not yet marked
                 const u32 e = plist[x]; if (!present(rw, e)) continue;
-                const u32 r2 = e & 0x7FFFFFFFu; if (rank[r2] == 0 || marked[r2]) continue;
+                const u32 r2 = e & IDM; if (rank[r2] == 0 || marked[r2]) continue;
                 explore_neighbours(widx[r2] - 1); marked[r2] = 1;
             }
         }
@@ -670,17 +671,18 @@ int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved
         WS(entp, u64, WS_RR_ENTP, totp + 64); WS(outp, u32, WS_RR_OUTP, totp + 64);
         HIPCHK(hipMemsetAsync(entp, 0, (totp + 64) * sizeof(u64), d->stream));
         if (nslots) hipLaunchKernelGGL(k_rr_fillp, dim3(grid_for(nslots, 256)), dim3(256), 0, d->stream, dh, (u64)nslots, d->reads, d->S, d->uniL, widx, offp, hitcount, pcur, entp);
-        hipLaunchKernelGGL(k_rr_sortp, dim3((unsigned)std::min<u64>((nun + 3) / 4, 256ull * 16)), dim3(256), 0, d->stream, (u64)nun, offp, degp, entp, outp, d->d_counters + 8 + 3);
+        hipLaunchKernelGGL(k_rr_sortp, dim3((unsigned)std::min<u64>((nun + 3) / 4, 256ull * 16)), dim3(256), 0, d->stream, (u64)nun, offp, degp, entp, outp, pcur, d->d_counters + 8 + 3);
         u64 over = 0; HIPCHK(hipMemcpyAsync(&over, d->d_counters + 8 + 3, sizeof over, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
         lap("potential lists (build + sort)");
         if (over) return 0;                                                       // a list beyond the device sort: serial replay
-        std::vector<u32> hIds(nun), hOff(nun + 1), hP(totp), hDeg(N + 2); std::vector<uint8_t> hasCand(nun, 0);
+        std::vector<u32> hIds(nun), hOff(nun + 1), hLen(nun), hP(totp), hDeg(N + 2); std::vector<uint8_t> hasCand(nun, 0);
+        HIPCHK(hipMemcpy(hLen.data(), pcur, nun * sizeof(u32), hipMemcpyDeviceToHost));                  // (the twin cursors are done with: reused for the list lengths)
         HIPCHK(hipMemcpy(hIds.data(), ids, nun * sizeof(u32), hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(hOff.data(), offp, nun * sizeof(u32), hipMemcpyDeviceToHost)); hOff[nun] = (u32)totp;
         if (totp) HIPCHK(hipMemcpy(hP.data(), outp, totp * sizeof(u32), hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(hDeg.data(), deg, (N + 2) * sizeof(u32), hipMemcpyDeviceToHost));     // so far: candidate entries only
         for (u64 w = 0; w < nun; w++) hasCand[w] = hDeg[hIds[w]] != 0;
         lap("potential lists -> host");
-        std::vector<u32> rankById; explore_order(hIds, hOff, hP, hasCand, N, rankById);
+        std::vector<u32> rankById; explore_order(hIds, hOff, hLen, hP, hasCand, N, rankById);
         lap("exploration order (host)");
         { WS(rk, u32, WS_RR_RANK, N + 2); rankDev = rk; }
         HIPCHK(hipMemcpy(rankDev, rankById.data(), (N + 2) * sizeof(u32), hipMemcpyHostToDevice));
