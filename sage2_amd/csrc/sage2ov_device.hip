@@ -34,7 +34,7 @@ typedef unsigned long long u64;
 typedef unsigned int u32;
 
 enum { WS_SLOTS, WS_CNT, WS_WHERE, WS_BIG, WS_CSR, WS_SLOW, WS_NEED, WS_DEG, WS_OFFS, WS_CURSOR, WS_KEYS, WS_KEEP, WS_POS, WS_OWNER, WS_FINAL,
-       WS_PARTIAL, WS_IDS, WS_NEAR, WS_HITS, WS_MINH, WS_OCNT, WS_OOFF, WS_OCUR, WS_ORDER, WS_MI1, WS_MICNT, WS_MICUR, WS_KREC, WS_SLOTMH, WS_RA_DEG, WS_RA_OFF, WS_RA_CUR, WS_RA_ENT, WS_RA_RM, WS_ORG_POOL, WS_ORG_OFF, WS_ORG_LEN, WS_ORG_IMG, WS_ORG_K0, WS_ORG_K1, WS_ORG_V0, WS_ORG_V1, WS_ORG_HIST, WS_ORG_HSCAN, WS_ORG_FLAG, WS_ORG_UID, WS_ORG_HEAD, WS_RR_IN, WS_RR_DEGP, WS_RR_OFFP, WS_RR_ENTP, WS_RR_OUTP, WS_RR_WIDX, WS_RR_RANK, WS_RR_CUR, WS_COUNT };   // ids of the workspace arena (Device::ws)
+       WS_PARTIAL, WS_IDS, WS_NEAR, WS_HITS, WS_MINH, WS_OCNT, WS_OOFF, WS_OCUR, WS_ORDER, WS_MI1, WS_MICNT, WS_MICUR, WS_KREC, WS_SLOTMH, WS_RA_DEG, WS_RA_OFF, WS_RA_CUR, WS_RA_ENT, WS_RA_RM, WS_ORG_POOL, WS_ORG_OFF, WS_ORG_LEN, WS_ORG_IMG, WS_ORG_K0, WS_ORG_K1, WS_ORG_V0, WS_ORG_V1, WS_ORG_HIST, WS_ORG_HSCAN, WS_ORG_FLAG, WS_ORG_UID, WS_ORG_HEAD, WS_RR_IN, WS_RR_DEGP, WS_RR_OFFP, WS_RR_ENTP, WS_RR_OUTP, WS_RR_WIDX, WS_RR_RANK, WS_RR_CUR, WS_RA_HEAVY, WS_RA_HSIZE, WS_RA_HSCR, WS_COUNT };   // ids of the workspace arena (Device::ws)
 struct Device {
     int ordinal = 0;
     hipStream_t stream = nullptr;
@@ -674,13 +674,32 @@ int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved
         hipLaunchKernelGGL(k_rr_sortp, dim3((unsigned)std::min<u64>((nun + 3) / 4, 256ull * 16)), dim3(256), 0, d->stream, (u64)nun, offp, degp, entp, outp, pcur, d->d_counters + 8 + 3);
         u64 over = 0; HIPCHK(hipMemcpyAsync(&over, d->d_counters + 8 + 3, sizeof over, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
         lap("potential lists (build + sort)");
-        if (over) return 0;                                                       // a list beyond the device sort: serial replay
+        if (timing) { std::vector<u32> hd(nun); HIPCHK(hipMemcpy(hd.data(), degp, nun * sizeof(u32), hipMemcpyDeviceToHost)); u64 c512 = 0, c1k = 0, c4k = 0; u32 mx = 0; for (u32 v : hd) { c512 += v > 512; c1k += v > 1024; c4k += v > 4096; mx = std::max(mx, v); }
+            fprintf(stderr, "[reduce/device] potential lists: %llu reads, > 512: %llu, > 1024: %llu, > 4096: %llu, longest %u\n", (unsigned long long)nun, (unsigned long long)c512, (unsigned long long)c1k, (unsigned long long)c4k, mx); }
         std::vector<u32> hIds(nun), hOff(nun + 1), hLen(nun), hP(totp), hDeg(N + 2); std::vector<uint8_t> hasCand(nun, 0);
         HIPCHK(hipMemcpy(hLen.data(), pcur, nun * sizeof(u32), hipMemcpyDeviceToHost));                  // (the twin cursors are done with: reused for the list lengths)
         HIPCHK(hipMemcpy(hIds.data(), ids, nun * sizeof(u32), hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(hOff.data(), offp, nun * sizeof(u32), hipMemcpyDeviceToHost)); hOff[nun] = (u32)totp;
         if (totp) HIPCHK(hipMemcpy(hP.data(), outp, totp * sizeof(u32), hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(hDeg.data(), deg, (N + 2) * sizeof(u32), hipMemcpyDeviceToHost));     // so far: candidate entries only
         for (u64 w = 0; w < nun; w++) hasCand[w] = hDeg[hIds[w]] != 0;
+        if (over) {                                                               // lists beyond the device sort (reads that thousands of others see): sorted and merged here
+            std::vector<u32> hDegp(nun); HIPCHK(hipMemcpy(hDegp.data(), degp, nun * sizeof(u32), hipMemcpyDeviceToHost));
+            std::vector<u64> seg;
+            for (u64 w = 0; w < nun; w++) {
+                const u32 n = hDegp[w]; if (n <= (u32)RR_CAP) continue;
+                seg.resize(n); HIPCHK(hipMemcpy(seg.data(), entp + hOff[w], (size_t)n * sizeof(u64), hipMemcpyDeviceToHost));
+                std::sort(seg.begin(), seg.end(), std::greater<u64>());
+                u32 len = 0;
+                for (u32 x = 0; x < n; x++) {
+                    const u64 kx = seg[x]; if (kx == 0) break;
+                    const bool twin = kx & 1ull;
+                    if (!twin && x > 0 && (seg[x - 1] & 1ull) && (seg[x - 1] >> 1) == (kx >> 1)) continue;      // the own hit behind its twin: merged
+                    const bool sym = twin && x + 1 < n && seg[x + 1] != 0 && !(seg[x + 1] & 1ull) && (seg[x + 1] >> 1) == (kx >> 1);
+                    hP[hOff[w] + len++] = (u32)(kx >> 11) | ((sym ? 0u : (twin ? 2u : 1u)) << 30);
+                }
+                hLen[w] = len;
+            }
+        }
         lap("potential lists -> host");
         std::vector<u32> rankById; explore_order(hIds, hOff, hLen, hP, hasCand, N, rankById);
         lap("exploration order (host)");
@@ -698,12 +717,27 @@ int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved
     HIPCHK(hipMemsetAsync(d->d_counters + 8, 0, 4 * sizeof(u64), d->stream));
     WS(svn, u32, WS_NEED, nun + 2); WS(svoff, u32, WS_OWNER, nun + 2);
     const unsigned gb = (unsigned)std::min<u64>((nun + 3) / 4, 256ull * 16);
-    hipLaunchKernelGGL(k_ra_mark, dim3(gb), dim3(256), 0, d->stream, ids, (u64)nun, offs, deg, ent, rm, svn, d->d_counters + 8);
-    u64 nsv = 0; { int rc = scan_u32(d, svn, nun, svoff, &nsv, err); if (rc) return rc; }
+    const u64 heavyCap = 1 << 16; WS(heavy, u32, WS_RA_HEAVY, heavyCap);
+    hipLaunchKernelGGL(k_ra_mark, dim3(gb), dim3(256), 0, d->stream, ids, (u64)nun, offs, deg, ent, rm, svn, d->d_counters + 8, heavy, heavyCap);
     u64 c[2];
     HIPCHK(hipMemcpyAsync(c, d->d_counters + 8, sizeof c, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
     HIPCHK(hipGetLastError());
-    if (c[0] != 0) return 0;                                              // a list does not fit the device kernel: serial replay
+    if (c[0] > heavyCap) return 0;                                        // (never seen) that many oversized lists: serial replay
+    if (c[0]) {                                                           // lists beyond the LDS kernel: same marking out of global scratch, one wavefront each
+        const u32 nhv = (u32)c[0];
+        WS(hsize, u32, WS_RA_HSIZE, nhv); WS(hscr, u64, WS_RA_HSCR, nhv);
+        hipLaunchKernelGGL(k_ra_heavy_sizes, dim3(grid_for(nhv, 256)), dim3(256), 0, d->stream, heavy, nhv, ids, deg, hsize);
+        std::vector<u32> hs(nhv); HIPCHK(hipMemcpy(hs.data(), hsize, nhv * sizeof(u32), hipMemcpyDeviceToHost));
+        std::vector<u64> so(nhv); u64 words = 0;
+        for (u32 b = 0; b < nhv; b++) { u64 P = 64; while (P < hs[b]) P <<= 1; so[b] = words; words += P + 2 * P + 2 * P; }      // key[P] u64 + ht[4P] u32 + mk[4P] u32
+        HIPCHK(hipMemcpy(hscr, so.data(), nhv * sizeof(u64), hipMemcpyHostToDevice));
+        u64* scratch = nullptr; HIPCHK(hipMalloc(&scratch, words * sizeof(u64)));
+        hipLaunchKernelGGL(k_ra_mark_big, dim3(nhv), dim3(64), 0, d->stream, ids, heavy, hscr, scratch, offs, deg, ent, rm, svn, d->d_counters + 8);
+        hipError_t e2 = hipStreamSynchronize(d->stream); hipFree(scratch);
+        if (e2 != hipSuccess) { err = std::string("k_ra_mark_big: ") + hipGetErrorString(e2); return SAGE2OV_ERR_DEVICE; }
+        HIPCHK(hipMemcpy(c, d->d_counters + 8, sizeof c, hipMemcpyDeviceToHost));
+    }
+    u64 nsv = 0; { int rc = scan_u32(d, svn, nun, svoff, &nsv, err); if (rc) return rc; }
     if (d->n_cand + nsv > d->cand_cap || getenv("SAGE2OV_TEST_SMALL_BUFFERS")) {
         EdgeCand* ncand = nullptr; const u64 ncap = d->n_cand + nsv + 1024;
         HIPCHK(hipMalloc(&ncand, ncap * sizeof(EdgeCand)));

@@ -3,7 +3,8 @@ import os, sys, time
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 import fixtures as fx, sage2_amd as s2
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
-for err, fam, copies in ((0, 4, 300), (1000, 4, 300), (1000, 0, 0)):
+cases = ((0, 4, 300), (1000, 4, 300), (1000, 0, 0)) if len(sys.argv) < 3 else ((1000, int(sys.argv[2]), 300),)
+for err, fam, copies in cases:
     pd = dict(seed=3, genome_len=3 * n, n_reads=n, read_len=150, err_ppm=err, n_repeat_families=fam, repeat_copies=copies, repeat_len=400)
     bases, off = fx.make_reads(pd)
     ctx = s2.Context(40); ctx.reads_add_ascii(bases, off); ctx.reads_organize()

@@ -589,3 +589,23 @@ def test_long_bucket_reduce_ranked_device_path_equals_serial_replay(monkeypatch)
     assert res["default"][4] > 0 and res["default"][3] > 100000
     assert res["default"][1:] == res["host"][1:]
     assert res["default"][0] == res["host"][0]
+
+
+def test_long_bucket_reduce_with_oversized_lists_equals_serial_replay(monkeypatch):
+    """a genome one quarter repeats: a few hundred unresolved reads next to the repeats are seen by thousands of others, so their potential
+    and final lists exceed what the LDS kernels hold (host-sorted potential lists, `k_ra_mark_big` out of global scratch) -- same edges
+    and counters as the serial replay"""
+    pd = dict(seed=3, genome_len=1500000, n_reads=500000, read_len=150, err_ppm=1000, n_repeat_families=12, repeat_copies=300, repeat_len=400)
+    bases, off = fx.make_reads(pd)
+    res = {}
+    for mode in ("default", "host"):
+        if mode == "host":
+            monkeypatch.setenv("SAGE2OV_HOST_REDUCE", "1")
+        else:
+            monkeypatch.delenv("SAGE2OV_HOST_REDUCE", raising=False)
+        ctx = s2.Context(40); ctx.reads_add_ascii(bases, off); ctx.reads_organize(); ctx.run_steps23()
+        st = ctx.overlap_stats(); res[mode] = (ctx.edges().tobytes(), st.edges_inserted, st.transitive_removed, st.left_to_explore, ctx.index_stats().long_buckets)
+        ctx.close()
+    assert res["default"][4] > 500 and res["default"][3] > 100000
+    assert res["default"][1:] == res["host"][1:]
+    assert res["default"][0] == res["host"][0]
