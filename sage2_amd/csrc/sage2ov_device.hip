@@ -553,20 +553,22 @@ int dev_unresolved_hits(Device* d, std::vector<Hit>& hits, uint64_t* n_unresolve
 // read is explored (:853-871); an entry is `to | twin << 31`.  An own hit is in the read's list iff the target was still unexplored
 // when the read was explored, a twin iff its source had been explored before; candidates of the reciprocal pass (hasCand) are always
 // there but their far ends are never explorable.  Returns rank[id] (1-based exploration order; 0: not an unresolved read).
-static void explore_order(const std::vector<u32>& ids, const std::vector<u32>& offp, const std::vector<u32>& lenp, const std::vector<u32>& plist, const std::vector<uint8_t>& hasCand,
+static void explore_order(const std::vector<u32>& ids, const std::vector<u32>& offp, const std::vector<u32>& lenp, const u32* plist, const std::vector<uint8_t>& hasCand,
                           u64 N, std::vector<u32>& rank) {
     const size_t n = ids.size();
     std::vector<u32> widx(N + 2, 0); for (size_t w = 0; w < n; w++) widx[ids[w]] = (u32)w + 1;
-    rank.assign(N + 2, 0);                                                       // by read id: 0 = unexplored (status 0), else 1-based exploration order
-    std::vector<uint8_t> marked(N + 2, 0);                                       // status 2 (:679)
+    // by read id: 0 = unexplored (status 0), else the 1-based exploration order, bit 31 = marked (status 2, :679) -- one table, one look-up
+    rank.assign(N + 2, 0);
+    constexpr u32 MARK = 0x80000000u, RK = 0x7FFFFFFFu;
     u32 ctr = 0;
     constexpr u32 IDM = 0x3FFFFFFFu;                                             // entry = to | kind << 30: 0 both sides see each other, 1 own hit only, 2 twin only
-    // one look-up per entry: an own-only hit is in the list iff its target was explored later (or not yet), a twin-only one iff its source was explored earlier
-    auto present = [&](u32 rw, u32 e) -> bool { const u32 k = e >> 30; if (k == 0) return true; const u32 rt = rank[e & IDM]; return k == 1 ? (rt == 0 || rt > rw) : (rt != 0 && rt < rw); };
+    // an own-only hit is in the list iff its target was explored later (or not yet), a twin-only one iff its source was explored earlier
+    auto present = [&](u32 rw, u32 e) -> bool { const u32 k = e >> 30; if (k == 0) return true; const u32 rt = rank[e & IDM] & RK; return k == 1 ? (rt == 0 || rt > rw) : (rt != 0 && rt < rw); };
     std::vector<u32> order(ids.begin(), ids.end()); std::sort(order.begin(), order.end());
     std::vector<u32> queue;
     auto explore_neighbours = [&](u32 w) {                                       // every still unexplored neighbour this read sees, in list order (:531-541)
         for (u32 x = offp[w], en = offp[w] + lenp[w]; x < en; x++) {
+            if (x + 16 < en) __builtin_prefetch(&rank[plist[x + 16] & IDM]);       // at 10 M reads the table (40 MB) is out of the caches
             const u32 e = plist[x]; if ((e >> 30) == 2) continue;
             const u32 to = e & IDM; if (rank[to] == 0) { rank[to] = ++ctr; queue.push_back(to); }
         }
@@ -577,18 +579,22 @@ static void explore_order(const std::vector<u32>& ids, const std::vector<u32>& o
         while (start < queue.size()) {
             const u32 r1 = queue[start++], w1 = widx[r1] - 1;
             if (rank[r1] == 0) rank[r1] = ++ctr;
-            const u32 rw = rank[r1], b1 = offp[w1], e1 = offp[w1] + lenp[w1];
+            const u32 rw = rank[r1] & RK, b1 = offp[w1], e1 = offp[w1] + lenp[w1];
             bool any = hasCand[w1] != 0;
             for (u32 x = b1; !any && x < e1; x++) any = present(rw, plist[x]);
             if (!any) continue;                                                  // an empty list (:527)
-            if (!marked[r1]) { explore_neighbours(w1); marked[r1] = 1; }
+            if (!(rank[r1] & MARK)) { explore_neighbours(w1); rank[r1] |= MARK; }
             for (u32 x = b1; x < e1; x++) {                                      // (:543-561) neighbours that are explored but not yet marked
-                const u32 e = plist[x]; if (!present(rw, e)) continue;
-                const u32 r2 = e & IDM; if (rank[r2] == 0 || marked[r2]) continue;
-                explore_neighbours(widx[r2] - 1); marked[r2] = 1;
+                if (x + 16 < e1) __builtin_prefetch(&rank[plist[x + 16] & IDM]);
+                const u32 e = plist[x], r2 = e & IDM, v2 = rank[r2];
+                if (v2 == 0 || (v2 & MARK)) continue;                            // unexplored, or marked already
+                const u32 k = e >> 30, rt = v2 & RK;
+                if (k == 1 ? !(rt > rw) : (k == 2 ? !(rt < rw) : false)) continue;  // not in this read's list
+                explore_neighbours(widx[r2] - 1); rank[r2] |= MARK;
             }
         }
     }
+    for (u32 id : ids) rank[id] &= RK;
 }
 
 int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved, uint64_t* n_hits, uint64_t* inserted, uint64_t* removed, int* done, std::string& err) {
@@ -676,10 +682,12 @@ int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved
         lap("potential lists (build + sort)");
         if (timing) { std::vector<u32> hd(nun); HIPCHK(hipMemcpy(hd.data(), degp, nun * sizeof(u32), hipMemcpyDeviceToHost)); u64 c512 = 0, c1k = 0, c4k = 0; u32 mx = 0; for (u32 v : hd) { c512 += v > 512; c1k += v > 1024; c4k += v > 4096; mx = std::max(mx, v); }
             fprintf(stderr, "[reduce/device] potential lists: %llu reads, > 512: %llu, > 1024: %llu, > 4096: %llu, longest %u\n", (unsigned long long)nun, (unsigned long long)c512, (unsigned long long)c1k, (unsigned long long)c4k, mx); }
-        std::vector<u32> hIds(nun), hOff(nun + 1), hLen(nun), hP(totp), hDeg(N + 2); std::vector<uint8_t> hasCand(nun, 0);
+        std::vector<u32> hIds(nun), hOff(nun + 1), hLen(nun), hDeg(N + 2); std::vector<uint8_t> hasCand(nun, 0);
+        struct Pinned { u32* p = nullptr; ~Pinned() { if (p) hipHostFree(p); } } pin;                      // gigabytes at 10 M reads: DMA into pinned memory, no zero fill
+        HIPCHK(hipHostMalloc((void**)&pin.p, (totp + 64) * sizeof(u32), hipHostMallocDefault)); u32* hP = pin.p;
         HIPCHK(hipMemcpy(hLen.data(), pcur, nun * sizeof(u32), hipMemcpyDeviceToHost));                  // (the twin cursors are done with: reused for the list lengths)
         HIPCHK(hipMemcpy(hIds.data(), ids, nun * sizeof(u32), hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(hOff.data(), offp, nun * sizeof(u32), hipMemcpyDeviceToHost)); hOff[nun] = (u32)totp;
-        if (totp) HIPCHK(hipMemcpy(hP.data(), outp, totp * sizeof(u32), hipMemcpyDeviceToHost));
+        if (totp) HIPCHK(hipMemcpy(hP, outp, totp * sizeof(u32), hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(hDeg.data(), deg, (N + 2) * sizeof(u32), hipMemcpyDeviceToHost));     // so far: candidate entries only
         for (u64 w = 0; w < nun; w++) hasCand[w] = hDeg[hIds[w]] != 0;
         if (over) {                                                               // lists beyond the device sort (reads that thousands of others see): sorted and merged here
