@@ -684,7 +684,9 @@ int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved
             fprintf(stderr, "[reduce/device] potential lists: %llu reads, > 512: %llu, > 1024: %llu, > 4096: %llu, longest %u\n", (unsigned long long)nun, (unsigned long long)c512, (unsigned long long)c1k, (unsigned long long)c4k, mx); }
         std::vector<u32> hIds(nun), hOff(nun + 1), hLen(nun), hDeg(N + 2); std::vector<uint8_t> hasCand(nun, 0);
         struct Pinned { u32* p = nullptr; ~Pinned() { if (p) hipHostFree(p); } } pin;                      // gigabytes at 10 M reads: DMA into pinned memory, no zero fill
-        HIPCHK(hipHostMalloc((void**)&pin.p, (totp + 64) * sizeof(u32), hipHostMallocDefault)); u32* hP = pin.p;
+        std::vector<u32> pageable; u32* hP = nullptr;
+        if (hipHostMalloc((void**)&pin.p, (totp + 64) * sizeof(u32), hipHostMallocDefault) == hipSuccess) hP = pin.p;
+        else { (void)hipGetLastError(); pin.p = nullptr; pageable.resize(totp + 64); hP = pageable.data(); }   // no pinned memory left: pageable staging
         HIPCHK(hipMemcpy(hLen.data(), pcur, nun * sizeof(u32), hipMemcpyDeviceToHost));                  // (the twin cursors are done with: reused for the list lengths)
         HIPCHK(hipMemcpy(hIds.data(), ids, nun * sizeof(u32), hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(hOff.data(), offp, nun * sizeof(u32), hipMemcpyDeviceToHost)); hOff[nun] = (u32)totp;
         if (totp) HIPCHK(hipMemcpy(hP, outp, totp * sizeof(u32), hipMemcpyDeviceToHost));
