@@ -385,7 +385,6 @@ int dev_probe(Device* d, uint64_t lo, uint64_t hi, std::string& err) {
     if (nreads && !seq_only) {
         WS(slow, u32, WS_SLOW, nreads);
         A.slow = slow; A.slow_cap = nreads;
-        const int nwinMax = d->maxL - d->h + 1;                               // windows of the longest read
         if (!getenv("SAGE2OV_NO_LOCALITY")) { u32* order = nullptr; int rc = build_locality_order(d, lo, hi, &order, err); if (rc) return rc; A.ids = order; A.n_ids = nreads; }
         const unsigned blocks = (unsigned)std::min<u64>((nreads + FAST_CHUNK - 1) / FAST_CHUNK, 256ull * 16);
 #ifdef SAGE2OV_STAMPS
@@ -517,7 +516,6 @@ int dev_download_status(Device* d, std::vector<uint8_t>& status, std::string& er
 int dev_unresolved_ids(Device* d, std::vector<uint32_t>& ids, std::string& err);
 int dev_unresolved_hits(Device* d, std::vector<Hit>& hits, uint64_t* n_unresolved, std::string& err) {
     HIPCHK(hipSetDevice(d->ordinal));
-    const u64 N = d->N;
     HIPCHK(hipEventRecord(d->ev[0], d->stream));
     std::vector<uint32_t> ids; int rc = dev_unresolved_ids(d, ids, err); if (rc) return rc;
     u64 nun = ids.size();
