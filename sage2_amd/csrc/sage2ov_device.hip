@@ -364,7 +364,7 @@ static bool launch_fast_any(Device* d, ProbeArgs& A, unsigned blocks) {
     const int nwinMax = d->maxL - d->h + 1;                               // windows of the longest read
     if (d->S == 4 && nwinMax <= 128) launch_fast<4, 8, 2, FW, HITS>(d, A, blocks);
     else if (d->S == 8 && d->maxL <= 160 && nwinMax <= 128) launch_fast<8, 10, 2, FW, HITS>(d, A, blocks);
-    else if (d->S == 8 && d->maxL <= 160) launch_fast<8, 10, 4, FW, HITS>(d, A, blocks);
+    else if (d->S == 8 && d->maxL <= 160) launch_fast<8, 10, 3, FW, HITS>(d, A, blocks);      // 129..160 windows, e.g. 150-bp reads with k <= 22
     else if (d->S == 8 && nwinMax <= 128) launch_fast<8, 16, 2, FW, HITS>(d, A, blocks);
     else if (d->S == 8) launch_fast<8, 16, 4, FW, HITS>(d, A, blocks);
     else return false;

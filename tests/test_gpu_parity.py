@@ -272,7 +272,8 @@ def test_cli_steps_1_to_3_write_reference_files(tmp_path):
 @pytest.mark.parametrize("pd,k", [
     (dict(seed=31, genome_len=30000, n_reads=9000, read_len=250, err_ppm=300), 40),        # 16-dword compare, 4 windows per lane
     (dict(seed=32, genome_len=30000, n_reads=9000, read_len=200, read_len_min=120, err_ppm=500), 31),   # mixed lengths in the long layout
-    (dict(seed=33, genome_len=24000, n_reads=8000, read_len=150, err_ppm=0), 21),          # 130 windows: 4 windows per lane, 10-dword compare
+    (dict(seed=33, genome_len=24000, n_reads=8000, read_len=150, err_ppm=0), 21),          # 130 windows: 3 windows per lane, 10-dword compare
+    (dict(seed=36, genome_len=24000, n_reads=8000, read_len=150, err_ppm=2000), 22),       # the same with read errors: in-kernel state machine with 3 windows per lane
     (dict(seed=34, genome_len=40000, n_reads=6000, read_len=300, err_ppm=300), 55),        # 16-word slots: sequential kernel only
     (dict(seed=35, genome_len=12000, n_reads=9000, read_len=60, err_ppm=0), 15),           # short reads, h < 16 (minimiser width = h)
 ])
