@@ -511,7 +511,9 @@ static int upload(sage2ov_ctx* c) {
     c->organized = true; c->indexBuilt = c->probed = c->reciprocalDone = c->reduced = c->converted = false;
     return SAGE2OV_OK;
 }
-static int choose_S(int maxL) { int need = (2 * maxL + 16 + 63) / 64; int S = 4; while (S < need) S *= 2; return S; }
+// a slot of S words holds the bases and, in the low 9 bits of its last word, the length: 123 / 251 / 507 bases for S = 4 / 8 / 16
+static constexpr uint64_t SLOT_LEN_MASK = 0x1FF;
+static int choose_S(int maxL) { int need = (2 * maxL + 9 + 63) / 64; int S = 4; while (S < need) S *= 2; return S; }
 
 int sage2ov_reads_organize(sage2ov_ctx* c) {                                          // readLoader.cpp:215-260
     if (!c) return SAGE2OV_ERR_ARG;
@@ -531,7 +533,7 @@ int sage2ov_reads_organize(sage2ov_ctx* c) {                                    
         if (rc) return rc;
         c->N = N; c->len.assign(N + 1, 0);
         #pragma omp parallel for
-        for (uint64_t i = 1; i <= N; i++) c->len[i] = (uint16_t)(c->words[i * c->S + c->S - 1] & 0xFFFF);
+        for (uint64_t i = 1; i <= N; i++) c->len[i] = (uint16_t)(c->words[i * c->S + c->S - 1] & SLOT_LEN_MASK);
         std::vector<uint64_t>().swap(c->pool); std::vector<uint64_t>().swap(c->poolOff); std::vector<uint16_t>().swap(c->poolLen);
         c->organized = true; c->indexBuilt = c->probed = c->reciprocalDone = c->reduced = c->converted = false;
         return SAGE2OV_OK;
@@ -569,7 +571,7 @@ int sage2ov_reads_organize(sage2ov_ctx* c) {                                    
         const uint32_t a = firstOf[i - 1]; const int L = pl[a], nw = (L + 31) / 32;
         uint64_t* w = &c->words[i * S];
         for (int q = 0; q < nw; q++) w[q] = pool[off[a] + q];
-        w[S - 1] |= (uint64_t)L;                                                       // length in the low 16 bits of the last word
+        w[S - 1] |= (uint64_t)L;                                                       // length in the low 9 bits of the last word
         c->len[i] = (uint16_t)L; c->freq[i] = fr[i - 1];
     }
     std::vector<uint64_t>().swap(c->pool); std::vector<uint64_t>().swap(c->poolOff); std::vector<uint16_t>().swap(c->poolLen);
@@ -605,7 +607,7 @@ int sage2ov_reads_save(sage2ov_ctx* c, const char* path) {                      
     const int S = c->S;
     int rc = write_formatted(c, f, c->N, (size_t)(2 * c->maxL + 24), [&](uint64_t x, std::string& o) {
         const uint64_t i = x + 1; const int L = c->len[i]; const uint64_t* w = &c->words[i * S];
-        uint64_t tmp[18], r[18]; const int nw = (L + 31) / 32; for (int q = 0; q < nw; q++) tmp[q] = w[q]; if (nw == S) tmp[nw - 1] &= ~0xFFFFull;
+        uint64_t tmp[18], r[18]; const int nw = (L + 31) / 32; for (int q = 0; q < nw; q++) tmp[q] = w[q]; if (nw == S) tmp[nw - 1] &= ~SLOT_LEN_MASK;
         revcomp_words(tmp, nw, L, r);
         char hd[48]; char* p = put_u(hd, c->freq[i]); *p++ = '\t'; p = put_u(p, (unsigned)L); *p++ = '\t';
         const size_t at = o.size(); o.resize(at + (size_t)(p - hd) + 2 * (size_t)L + 2);
@@ -650,7 +652,7 @@ int sage2ov_reads_import_words(sage2ov_ctx* c, const uint64_t* words, uint64_t n
     c->N = n_unique; c->S = (int)words_per_read; c->maxL = (int)max_read_length;
     c->words.assign(words, words + (n_unique + 1) * words_per_read);
     c->len.assign(n_unique + 1, 0); c->freq.assign(n_unique + 1, 0);
-    for (uint64_t i = 1; i <= n_unique; i++) { c->len[i] = (uint16_t)(c->words[i * c->S + c->S - 1] & 0xFFFF); c->freq[i] = frequency ? frequency[i] : 1; }
+    for (uint64_t i = 1; i <= n_unique; i++) { c->len[i] = (uint16_t)(c->words[i * c->S + c->S - 1] & SLOT_LEN_MASK); c->freq[i] = frequency ? frequency[i] : 1; }
     c->goodReads = good_reads; c->totalBP = total_bp; c->totalReads = good_reads; c->organized = false;
     return upload(c);
 }

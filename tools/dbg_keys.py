@@ -24,7 +24,7 @@ def bits(w, pos, n):   # n bits from bit pos of big-endian word array
 bad = 0
 h = min(m["k"], 64)
 for i in list(range(1, 200)) + list(range(N - 5000, N + 1)):
-    w = words[i * S:(i + 1) * S]; L = int(w[S - 1]) & 0xFFFF
+    w = words[i * S:(i + 1) * S]; L = int(w[S - 1]) & 0x1FF
     pre = bits(w, 0, 2 * h); suf = bits(w, 2 * (L - h), 2 * h)
     def rck(v):
         r = 0
