@@ -229,3 +229,29 @@ def test_full_size_properties_c2(tmp_path):
     ctx.graph_simplify(); out2 = str(tmp_path / "u.graph4"); ctx.graph4_save(out2)
     assert zlib.crc32(open(out2, "rb").read()) == crc
     ctx.close()
+
+
+def test_cli_end_to_end_fastq_250bp_against_both_oracles(tmp_path):
+    """one run through everything: a 5 MB four-line FASTQ of 250-bp reads with errors (chunk-parallel reader, 8-word slots with the 16-dword
+    compare, sequential-kernel hand-overs, device reduce), `sage2ov -M 4 -s`; P.reads / P.graph3 against the steps 1-3 oracle, P.graph4
+    against the step-4 oracle"""
+    import subprocess
+    import oracle_lib as ol
+    pd = dict(seed=61, genome_len=100000, n_reads=20000, read_len=250, err_ppm=1500)
+    bases, off = fx.make_reads(pd)
+    fq = str(tmp_path / "x.fq")
+    with open(fq, "w") as f:
+        for i in range(len(off) - 1):
+            s = bytes(bases[int(off[i]):int(off[i + 1])]).decode()
+            f.write(f"@r{i}\n{s}\n+\n{'@' * len(s)}\n")
+    assert os.path.getsize(fq) > (1 << 20)
+    exe = os.path.join(ROOT, "sage2_amd", "sage2ov"); out = str(tmp_path / "out")
+    subprocess.run([exe, "-f", fq, "-k", "45", "-o", out, "-p", "t", "-M", "4", "-s"], check=True, stdout=subprocess.DEVNULL)
+    o = ol.Oracle(45, 8); o.add_reads_ascii(bases, off); o.organize(); o.run_all()
+    o.write_reads(str(tmp_path / "o.reads")); o.write_graph3(str(tmp_path / "o.graph3")); n = o.counter("N"); o.close()
+    assert open(os.path.join(out, "t.reads"), "rb").read() == open(tmp_path / "o.reads", "rb").read()
+    assert open(os.path.join(out, "t.graph3"), "rb").read() == open(tmp_path / "o.graph3", "rb").read()
+    c = (ctypes.c_ulonglong * 5)(); ref = str(tmp_path / "ref.graph4")
+    assert _oracle4().orc4_run_files(str(tmp_path / "o.graph3").encode(), n, ref.encode(), c) == 0
+    got, want = open(os.path.join(out, "t.graph4"), "rb").read(), open(ref, "rb").read()
+    assert got == want, _first_diff(got, want)
