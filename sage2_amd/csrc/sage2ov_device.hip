@@ -365,8 +365,9 @@ static bool launch_fast_any(Device* d, ProbeArgs& A, unsigned blocks) {
     if (d->S == 4 && nwinMax <= 128) launch_fast<4, 8, 2, FW, HITS>(d, A, blocks);
     else if (d->S == 8 && d->maxL <= 160 && nwinMax <= 128) launch_fast<8, 10, 2, FW, HITS>(d, A, blocks);
     else if (d->S == 8 && d->maxL <= 160) launch_fast<8, 10, 3, FW, HITS>(d, A, blocks);      // 129..160 windows, e.g. 150-bp reads with k <= 22
-    else if (d->S == 8 && nwinMax <= 128) launch_fast<8, 16, 2, FW, HITS>(d, A, blocks);
-    else if (d->S == 8) launch_fast<8, 16, 4, FW, HITS>(d, A, blocks);
+    // (the 16-dword layout's state-machine rows take 12 KB of LDS per wave: four waves per block keep three blocks on a CU)
+    else if (d->S == 8 && nwinMax <= 128) launch_fast<8, 16, 2, (HITS ? FW : 4), HITS>(d, A, blocks);
+    else if (d->S == 8) launch_fast<8, 16, 4, (HITS ? FW : 4), HITS>(d, A, blocks);
     else return false;
     return true;
 }
