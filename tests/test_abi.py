@@ -186,3 +186,15 @@ def test_parallel_file_reader_equals_sequential_reader(form, tmp_path, monkeypat
     (pb, lb, fb), sb = _export(path, 21, True, monkeypatch)
     assert sa == sb and sa[1] > 0.5 * n
     assert np.array_equal(pa, pb) and np.array_equal(la, lb) and np.array_equal(fa, fb)
+
+
+def test_step4_needs_the_gpu():
+    """no CPU fallback: a context without a device refuses steps 2-4 (here: step 4 and the edge import) with SAGE2OV_ERR_DEVICE"""
+    ctx = s2.Context(21, device=-2)
+    bases = np.frombuffer(b"ACGTACGTTGCAAGCTAGCTAGGATCCATGCA" * 2, dtype=np.uint8).copy(); off = np.array([0, 32, 64], dtype=np.uint64)
+    ctx.reads_add_ascii(bases, off); ctx.reads_organize()
+    for call in (ctx.graph_simplify, lambda: ctx.edges_import(np.zeros(0, dtype=s2.EDGE_DTYPE))):
+        with pytest.raises(s2.Sage2ovError) as ei:
+            call()
+        assert ei.value.code == -3
+    ctx.close()
