@@ -612,3 +612,28 @@ def test_long_bucket_reduce_with_oversized_lists_equals_serial_replay(monkeypatc
     assert res["default"][4] > 500 and res["default"][3] > 100000
     assert res["default"][1:] == res["host"][1:]
     assert res["default"][0] == res["host"][0]
+
+
+@pytest.mark.parametrize("pd,k", [
+    (dict(seed=81, genome_len=400000, n_reads=150000, read_len=150, read_len_min=80, err_ppm=2000, n_repeat_families=6, repeat_copies=200, repeat_len=300), 31),   # mixed lengths: containment + long buckets
+    (dict(seed=82, genome_len=300000, n_reads=150000, read_len=100, err_ppm=500, n_repeat_families=3, repeat_copies=400, repeat_len=120), 21),                    # short repeats inside reads, k=21
+    (dict(seed=83, genome_len=700000, n_reads=160000, read_len=250, err_ppm=1500, n_repeat_families=2, repeat_copies=600, repeat_len=300), 55),                   # 250-bp reads, 16-dword layout
+])
+def test_long_bucket_reduce_more_shapes_equal_serial_replay(pd, k, monkeypatch):
+    """the ranked device reduce against the serial replay on other shapes of data: mixed read lengths (containment marks next to
+    long buckets), repeats shorter than a read, the long layout"""
+    bases, off = fx.make_reads(pd)
+    res = {}
+    for mode in ("default", "host"):
+        if mode == "host":
+            monkeypatch.setenv("SAGE2OV_HOST_REDUCE", "1")
+        else:
+            monkeypatch.delenv("SAGE2OV_HOST_REDUCE", raising=False)
+            monkeypatch.setenv("SAGE2OV_DEVICE_REDUCE_MIN", "1")
+        ctx = s2.Context(k); ctx.reads_add_ascii(bases, off); ctx.reads_organize(); ctx.run_steps23()
+        st = ctx.overlap_stats(); res[mode] = (ctx.edges().tobytes(), st.edges_inserted, st.transitive_removed, st.left_to_explore, ctx.index_stats().long_buckets)
+        ctx.close()
+        monkeypatch.delenv("SAGE2OV_DEVICE_REDUCE_MIN", raising=False)
+    assert res["default"][4] > 0 and res["default"][3] > 1000
+    assert res["default"][1:] == res["host"][1:]
+    assert res["default"][0] == res["host"][0]
