@@ -34,7 +34,7 @@ typedef unsigned long long u64;
 typedef unsigned int u32;
 
 enum { WS_SLOTS, WS_CNT, WS_WHERE, WS_BIG, WS_CSR, WS_SLOW, WS_NEED, WS_DEG, WS_OFFS, WS_CURSOR, WS_KEYS, WS_KEEP, WS_POS, WS_OWNER, WS_FINAL,
-       WS_PARTIAL, WS_IDS, WS_NEAR, WS_HITS, WS_MINH, WS_OCNT, WS_OOFF, WS_OCUR, WS_ORDER, WS_MI1, WS_MICNT, WS_MICUR, WS_KREC, WS_SLOTMH, WS_RA_DEG, WS_RA_OFF, WS_RA_CUR, WS_RA_ENT, WS_RA_RM, WS_ORG_POOL, WS_ORG_OFF, WS_ORG_LEN, WS_ORG_IMG, WS_ORG_K0, WS_ORG_K1, WS_ORG_V0, WS_ORG_V1, WS_ORG_HIST, WS_ORG_HSCAN, WS_ORG_FLAG, WS_ORG_UID, WS_ORG_HEAD, WS_RR_IN, WS_RR_DEGP, WS_RR_OFFP, WS_RR_ENTP, WS_RR_OUTP, WS_RR_WIDX, WS_RR_RANK, WS_RR_CUR, WS_RA_HEAVY, WS_RA_HSIZE, WS_RA_HSCR, WS_COUNT };   // ids of the workspace arena (Device::ws)
+       WS_PARTIAL, WS_IDS, WS_NEAR, WS_HITS, WS_MINH, WS_OCNT, WS_OOFF, WS_OCUR, WS_ORDER, WS_MI1, WS_MICNT, WS_MICUR, WS_KREC, WS_SLOTMH, WS_RA_DEG, WS_RA_OFF, WS_RA_CUR, WS_RA_ENT, WS_RA_RM, WS_ORG_POOL, WS_ORG_OFF, WS_ORG_LEN, WS_ORG_IMG, WS_ORG_K0, WS_ORG_K1, WS_ORG_V0, WS_ORG_V1, WS_ORG_HIST, WS_ORG_HSCAN, WS_ORG_FLAG, WS_ORG_UID, WS_ORG_HEAD, WS_RR_IN, WS_RR_DEGP, WS_RR_OFFP, WS_RR_ENTP, WS_RR_OUTP, WS_RR_WIDX, WS_RR_RANK, WS_RR_CUR, WS_RA_HEAVY, WS_RA_HSIZE, WS_RA_HSCR, WS_RR_LEN, WS_RR_COFF, WS_RR_OUTC, WS_COUNT };   // ids of the workspace arena (Device::ws)
 struct Device {
     int ordinal = 0;
     hipStream_t stream = nullptr;
@@ -552,10 +552,13 @@ int dev_unresolved_hits(Device* d, std::vector<Hit>& hits, uint64_t* n_unresolve
 // read is explored (:853-871); an entry is `to | twin << 31`.  An own hit is in the read's list iff the target was still unexplored
 // when the read was explored, a twin iff its source had been explored before; candidates of the reciprocal pass (hasCand) are always
 // there but their far ends are never explorable.  Returns rank[id] (1-based exploration order; 0: not an unresolved read).
-static void explore_order(const std::vector<u32>& ids, const std::vector<u32>& offp, const std::vector<u32>& lenp, const u32* plist, const std::vector<uint8_t>& hasCand,
+static void explore_order(const std::vector<u32>& ids, const std::vector<const u32*>& lists, const std::vector<u32>& lenp, const std::vector<uint8_t>& hasCand,
                           u64 N, std::vector<u32>& rank) {
     const size_t n = ids.size();
-    std::vector<u32> widx(N + 2, 0); for (size_t w = 0; w < n; w++) widx[ids[w]] = (u32)w + 1;
+    // per read id: where its list is, how long, whether candidates of the reciprocal pass hang on it -- one 16-byte record, one cache line per visit
+    struct PL { const u32* p; u32 n; u32 cand; };
+    std::vector<PL> pl(N + 2, PL{nullptr, 0, 0});
+    for (size_t w = 0; w < n; w++) pl[ids[w]] = PL{lists[w], lenp[w], hasCand[w]};
     // by read id: 0 = unexplored (status 0), else the 1-based exploration order, bit 31 = marked (status 2, :679) -- one table, one look-up
     rank.assign(N + 2, 0);
     constexpr u32 MARK = 0x80000000u, RK = 0x7FFFFFFFu;
@@ -565,8 +568,9 @@ static void explore_order(const std::vector<u32>& ids, const std::vector<u32>& o
     auto present = [&](u32 rw, u32 e) -> bool { const u32 k = e >> 30; if (k == 0) return true; const u32 rt = rank[e & IDM] & RK; return k == 1 ? (rt == 0 || rt > rw) : (rt != 0 && rt < rw); };
     std::vector<u32> order(ids.begin(), ids.end()); std::sort(order.begin(), order.end());
     std::vector<u32> queue;
-    auto explore_neighbours = [&](u32 w) {                                       // every still unexplored neighbour this read sees, in list order (:531-541)
-        for (u32 x = offp[w], en = offp[w] + lenp[w]; x < en; x++) {
+    auto explore_neighbours = [&](u32 r) {                                       // every still unexplored neighbour this read sees, in list order (:531-541)
+        const u32* plist = pl[r].p;
+        for (u32 x = 0, en = pl[r].n; x < en; x++) {
             if (x + 16 < en) __builtin_prefetch(&rank[plist[x + 16] & IDM]);       // at 10 M reads the table (40 MB) is out of the caches
             const u32 e = plist[x]; if ((e >> 30) == 2) continue;
             const u32 to = e & IDM; if (rank[to] == 0) { rank[to] = ++ctr; queue.push_back(to); }
@@ -576,20 +580,20 @@ static void explore_order(const std::vector<u32>& ids, const std::vector<u32>& o
         if (rank[id0] != 0) continue;
         queue.clear(); size_t start = 0; queue.push_back(id0);
         while (start < queue.size()) {
-            const u32 r1 = queue[start++], w1 = widx[r1] - 1;
+            const u32 r1 = queue[start++];
             if (rank[r1] == 0) rank[r1] = ++ctr;
-            const u32 rw = rank[r1] & RK, b1 = offp[w1], e1 = offp[w1] + lenp[w1];
-            bool any = hasCand[w1] != 0;
+            const u32 rw = rank[r1] & RK, b1 = 0, e1 = pl[r1].n; const u32* plist = pl[r1].p;
+            bool any = pl[r1].cand != 0;
             for (u32 x = b1; !any && x < e1; x++) any = present(rw, plist[x]);
             if (!any) continue;                                                  // an empty list (:527)
-            if (!(rank[r1] & MARK)) { explore_neighbours(w1); rank[r1] |= MARK; }
+            if (!(rank[r1] & MARK)) { explore_neighbours(r1); rank[r1] |= MARK; }
             for (u32 x = b1; x < e1; x++) {                                      // (:543-561) neighbours that are explored but not yet marked
                 if (x + 16 < e1) __builtin_prefetch(&rank[plist[x + 16] & IDM]);
                 const u32 e = plist[x], r2 = e & IDM, v2 = rank[r2];
                 if (v2 == 0 || (v2 & MARK)) continue;                            // unexplored, or marked already
                 const u32 k = e >> 30, rt = v2 & RK;
                 if (k == 1 ? !(rt > rw) : (k == 2 ? !(rt < rw) : false)) continue;  // not in this read's list
-                explore_neighbours(widx[r2] - 1); rank[r2] |= MARK;
+                explore_neighbours(r2); rank[r2] |= MARK;
             }
         }
     }
@@ -665,52 +669,67 @@ int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved
     u32* rankDev = nullptr; u64 present = 0;
     HIPCHK(hipMemsetAsync(d->d_counters + 8, 0, 4 * sizeof(u64), d->stream));
     if (ranked) {
-        // potential lists (own hits + twins of incoming hits), sorted on the device; exploration order on the host; ranks back
-        WS(incount, u32, WS_RR_IN, N + 2); WS(widx, u32, WS_RR_WIDX, N + 2); WS(degp, u32, WS_RR_DEGP, nun + 2); WS(offp, u32, WS_RR_OFFP, nun + 2); WS(pcur, u32, WS_RR_CUR, N + 2);
+        // potential lists (own hits + twins of incoming hits), sorted and merged on the device, slice by slice (a slice stays below 2^30
+        // entries); exploration order on the host; ranks back
+        WS(incount, u32, WS_RR_IN, N + 2); WS(widx, u32, WS_RR_WIDX, N + 2); WS(degp, u32, WS_RR_DEGP, nun + 2); WS(pcur, u32, WS_RR_CUR, N + 2);
         HIPCHK(hipMemsetAsync(incount, 0, (N + 2) * sizeof(u32), d->stream)); HIPCHK(hipMemsetAsync(pcur, 0, (N + 2) * sizeof(u32), d->stream));
         hipLaunchKernelGGL(k_rr_widx, dim3(grid_for(nun, 256)), dim3(256), 0, d->stream, ids, (u64)nun, widx);
         if (nslots) hipLaunchKernelGGL(k_rr_incount, dim3(grid_for(nslots, 256)), dim3(256), 0, d->stream, dh, (u64)nslots, incount);
         hipLaunchKernelGGL(k_rr_degp, dim3(grid_for(nun, 256)), dim3(256), 0, d->stream, ids, (u64)nun, hitcount, incount, degp);
-        u64 totp = 0; { int rc = scan_u32(d, degp, nun, offp, &totp, err); if (rc) return rc; }
-        if (totp >= (1ull << 32) - 64) return 0;
-        WS(entp, u64, WS_RR_ENTP, totp + 64); WS(outp, u32, WS_RR_OUTP, totp + 64);
-        HIPCHK(hipMemsetAsync(entp, 0, (totp + 64) * sizeof(u64), d->stream));
-        if (nslots) hipLaunchKernelGGL(k_rr_fillp, dim3(grid_for(nslots, 256)), dim3(256), 0, d->stream, dh, (u64)nslots, d->reads, d->S, d->uniL, widx, offp, hitcount, pcur, entp);
-        hipLaunchKernelGGL(k_rr_sortp, dim3((unsigned)std::min<u64>((nun + 3) / 4, 256ull * 16)), dim3(256), 0, d->stream, (u64)nun, offp, degp, entp, outp, pcur, d->d_counters + 8 + 3);
-        u64 over = 0; HIPCHK(hipMemcpyAsync(&over, d->d_counters + 8 + 3, sizeof over, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
-        lap("potential lists (build + sort)");
-        if (timing) { std::vector<u32> hd(nun); HIPCHK(hipMemcpy(hd.data(), degp, nun * sizeof(u32), hipMemcpyDeviceToHost)); u64 c512 = 0, c1k = 0, c4k = 0; u32 mx = 0; for (u32 v : hd) { c512 += v > 512; c1k += v > 1024; c4k += v > 4096; mx = std::max(mx, v); }
-            fprintf(stderr, "[reduce/device] potential lists: %llu reads, > 512: %llu, > 1024: %llu, > 4096: %llu, longest %u\n", (unsigned long long)nun, (unsigned long long)c512, (unsigned long long)c1k, (unsigned long long)c4k, mx); }
-        std::vector<u32> hIds(nun), hOff(nun + 1), hLen(nun), hDeg(N + 2); std::vector<uint8_t> hasCand(nun, 0);
-        struct Pinned { u32* p = nullptr; ~Pinned() { if (p) hipHostFree(p); } } pin;                      // gigabytes at 10 M reads: DMA into pinned memory, no zero fill
-        std::vector<u32> pageable; u32* hP = nullptr;
-        if (hipHostMalloc((void**)&pin.p, (totp + 64) * sizeof(u32), hipHostMallocDefault) == hipSuccess) hP = pin.p;
-        else { (void)hipGetLastError(); pin.p = nullptr; pageable.resize(totp + 64); hP = pageable.data(); }   // no pinned memory left: pageable staging
-        HIPCHK(hipMemcpy(hLen.data(), pcur, nun * sizeof(u32), hipMemcpyDeviceToHost));                  // (the twin cursors are done with: reused for the list lengths)
-        HIPCHK(hipMemcpy(hIds.data(), ids, nun * sizeof(u32), hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(hOff.data(), offp, nun * sizeof(u32), hipMemcpyDeviceToHost)); hOff[nun] = (u32)totp;
-        if (totp) HIPCHK(hipMemcpy(hP, outp, totp * sizeof(u32), hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(hDeg.data(), deg, (N + 2) * sizeof(u32), hipMemcpyDeviceToHost));     // so far: candidate entries only
+        std::vector<u32> hIds(nun), hLen(nun, 0), hDeg(N + 2), hDegp(nun); std::vector<uint8_t> hasCand(nun, 0); std::vector<const u32*> listPtr(nun, nullptr);
+        HIPCHK(hipMemcpyAsync(hDegp.data(), degp, nun * sizeof(u32), hipMemcpyDeviceToHost, d->stream));
+        HIPCHK(hipMemcpyAsync(hIds.data(), ids, nun * sizeof(u32), hipMemcpyDeviceToHost, d->stream));
+        HIPCHK(hipMemcpyAsync(hDeg.data(), deg, (N + 2) * sizeof(u32), hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));   // (deg so far: candidate entries only)
         for (u64 w = 0; w < nun; w++) hasCand[w] = hDeg[hIds[w]] != 0;
-        if (over) {                                                               // lists beyond the device sort (reads that thousands of others see): sorted and merged here
-            std::vector<u32> hDegp(nun); HIPCHK(hipMemcpy(hDegp.data(), degp, nun * sizeof(u32), hipMemcpyDeviceToHost));
-            std::vector<u64> seg;
-            for (u64 w = 0; w < nun; w++) {
-                const u32 n = hDegp[w]; if (n <= (u32)RR_CAP) continue;
-                seg.resize(n); HIPCHK(hipMemcpy(seg.data(), entp + hOff[w], (size_t)n * sizeof(u64), hipMemcpyDeviceToHost));
-                std::sort(seg.begin(), seg.end(), std::greater<u64>());
-                u32 len = 0;
-                for (u32 x = 0; x < n; x++) {
-                    const u64 kx = seg[x]; if (kx == 0) break;
-                    const bool twin = kx & 1ull;
-                    if (!twin && x > 0 && (seg[x - 1] & 1ull) && (seg[x - 1] >> 1) == (kx >> 1)) continue;      // the own hit behind its twin: merged
-                    const bool sym = twin && x + 1 < n && seg[x + 1] != 0 && !(seg[x + 1] & 1ull) && (seg[x + 1] >> 1) == (kx >> 1);
-                    hP[hOff[w] + len++] = (u32)(kx >> 11) | ((sym ? 0u : (twin ? 2u : 1u)) << 30);
+        if (timing) { u64 c512 = 0, c1k = 0, c4k = 0; u32 mx = 0; for (u32 v : hDegp) { c512 += v > 512; c1k += v > 1024; c4k += v > 4096; mx = std::max(mx, v); }
+            fprintf(stderr, "[reduce/device] potential lists: %llu reads, > 512: %llu, > 1024: %llu, > 4096: %llu, longest %u\n", (unsigned long long)nun, (unsigned long long)c512, (unsigned long long)c1k, (unsigned long long)c4k, mx); }
+        struct Staging { std::vector<u32*> pinned; std::vector<std::vector<u32>> pageable; ~Staging() { for (u32* p : pinned) hipHostFree(p); }
+                         u32* get(size_t n) { u32* p = nullptr; if (hipHostMalloc((void**)&p, std::max<size_t>(n, 16) * sizeof(u32), hipHostMallocDefault) == hipSuccess) { pinned.push_back(p); return p; }
+                                              (void)hipGetLastError(); pageable.emplace_back(std::max<size_t>(n, 16)); return pageable.back().data(); } } staging;   // gigabytes at 10 M reads: DMA into pinned memory when there is some
+        std::vector<std::vector<u32>> heavyLists;                                 // lists beyond the device sort (reads that thousands of others see): sorted and merged on the host
+        u64 sliceEntries = 1ull << 30; if (const char* ev = getenv("SAGE2OV_TEST_RANK_SLICE")) sliceEntries = std::max<u64>(1024, strtoull(ev, nullptr, 10));
+        WS(lenp, u32, WS_RR_LEN, nun + 2);
+        for (u64 w0 = 0; w0 < nun;) {
+            u64 w1 = w0, tot0 = 0; while (w1 < nun && (w1 == w0 || tot0 + hDegp[w1] <= sliceEntries)) tot0 += hDegp[w1++];
+            if (tot0 >= (1ull << 32) - 64) return 0;                              // one read with 2^32 potential neighbours: not this path
+            const u64 nw = w1 - w0;
+            WS(offp, u32, WS_RR_OFFP, nw + 2); WS(coff, u32, WS_RR_COFF, nw + 2);
+            u64 totp = 0; { int rc = scan_u32(d, degp + w0, nw, offp, &totp, err); if (rc) return rc; }
+            WS(entp, u64, WS_RR_ENTP, totp + 64); WS(outp, u32, WS_RR_OUTP, totp + 64);
+            HIPCHK(hipMemsetAsync(entp, 0, (totp + 64) * sizeof(u64), d->stream));
+            if (nslots) hipLaunchKernelGGL(k_rr_fillp, dim3(grid_for(nslots, 256)), dim3(256), 0, d->stream, dh, (u64)nslots, d->reads, d->S, d->uniL, widx, (u32)w0, (u32)w1, offp, hitcount, pcur, entp);
+            hipLaunchKernelGGL(k_rr_sortp, dim3((unsigned)std::min<u64>((nw + 3) / 4, 256ull * 16)), dim3(256), 0, d->stream, (u64)nw, offp, degp + w0, entp, outp, lenp + w0, d->d_counters + 8 + 3);
+            u64 totc = 0; { int rc = scan_u32(d, lenp + w0, nw, coff, &totc, err); if (rc) return rc; }
+            WS(outc, u32, WS_RR_OUTC, totc + 64);
+            hipLaunchKernelGGL(k_rr_compact, dim3((unsigned)std::min<u64>((nw + 3) / 4, 256ull * 16)), dim3(256), 0, d->stream, (u64)nw, offp, lenp + w0, coff, outp, outc);
+            u32* hbuf = staging.get(totc);
+            HIPCHK(hipMemcpyAsync(hLen.data() + w0, lenp + w0, nw * sizeof(u32), hipMemcpyDeviceToHost, d->stream));
+            if (totc) HIPCHK(hipMemcpyAsync(hbuf, outc, totc * sizeof(u32), hipMemcpyDeviceToHost, d->stream));
+            HIPCHK(hipStreamSynchronize(d->stream));
+            u64 at = 0, rel = 0; std::vector<u64> seg;
+            for (u64 w = w0; w < w1; w++) {
+                const u32 n = hDegp[w];
+                if (n <= (u32)RR_CAP) { listPtr[w] = hbuf + at; at += hLen[w]; }
+                else {                                                            // (its device length is 0)
+                    seg.resize(n); HIPCHK(hipMemcpy(seg.data(), entp + rel, (size_t)n * sizeof(u64), hipMemcpyDeviceToHost));
+                    std::sort(seg.begin(), seg.end(), std::greater<u64>());
+                    heavyLists.emplace_back(); std::vector<u32>& hl = heavyLists.back(); hl.reserve(n);
+                    for (u32 x = 0; x < n; x++) {
+                        const u64 kx = seg[x]; if (kx == 0) break;
+                        const bool twin = kx & 1ull;
+                        if (!twin && x > 0 && (seg[x - 1] & 1ull) && (seg[x - 1] >> 1) == (kx >> 1)) continue;      // the own hit behind its twin: merged
+                        const bool sym = twin && x + 1 < n && seg[x + 1] != 0 && !(seg[x + 1] & 1ull) && (seg[x + 1] >> 1) == (kx >> 1);
+                        hl.push_back((u32)(kx >> 11) | ((sym ? 0u : (twin ? 2u : 1u)) << 30));
+                    }
+                    hLen[w] = (u32)hl.size();
                 }
-                hLen[w] = len;
+                rel += n;
             }
+            w0 = w1;
         }
-        lap("potential lists -> host");
-        std::vector<u32> rankById; explore_order(hIds, hOff, hLen, hP, hasCand, N, rankById);
+        { size_t hx = 0; for (u64 w = 0; w < nun; w++) if (hDegp[w] > (u32)RR_CAP) listPtr[w] = heavyLists[hx++].data(); }      // (after the last push_back: the vectors no longer move)
+        lap("potential lists (build + sort + download)");
+        std::vector<u32> rankById; explore_order(hIds, listPtr, hLen, hasCand, N, rankById);
         lap("exploration order (host)");
         { WS(rk, u32, WS_RR_RANK, N + 2); rankDev = rk; }
         HIPCHK(hipMemcpy(rankDev, rankById.data(), (N + 2) * sizeof(u32), hipMemcpyHostToDevice));

@@ -637,3 +637,20 @@ def test_long_bucket_reduce_more_shapes_equal_serial_replay(pd, k, monkeypatch):
     assert res["default"][4] > 0 and res["default"][3] > 1000
     assert res["default"][1:] == res["host"][1:]
     assert res["default"][0] == res["host"][0]
+
+
+def test_long_bucket_reduce_in_many_slices(monkeypatch):
+    """the potential lists are built for a slice of the unresolved reads at a time (2^30 entries per slice; 50 M noisy reads need five):
+    here with slices of 200 k entries, i.e. dozens of them, against the serial replay"""
+    pd = dict(seed=3, genome_len=1500000, n_reads=500000, read_len=150, err_ppm=1000, n_repeat_families=12, repeat_copies=300, repeat_len=400)
+    bases, off = fx.make_reads(pd)
+    res = {}
+    for mode in ("sliced", "host"):
+        if mode == "host":
+            monkeypatch.setenv("SAGE2OV_HOST_REDUCE", "1")
+        else:
+            monkeypatch.delenv("SAGE2OV_HOST_REDUCE", raising=False); monkeypatch.setenv("SAGE2OV_TEST_RANK_SLICE", "200000")
+        ctx = s2.Context(40); ctx.reads_add_ascii(bases, off); ctx.reads_organize(); ctx.run_steps23()
+        st = ctx.overlap_stats(); res[mode] = (ctx.edges().tobytes(), st.edges_inserted, st.transitive_removed, st.left_to_explore)
+        ctx.close(); monkeypatch.delenv("SAGE2OV_TEST_RANK_SLICE", raising=False)
+    assert res["sliced"][1:] == res["host"][1:] and res["sliced"][0] == res["host"][0]
