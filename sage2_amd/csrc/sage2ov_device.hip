@@ -558,7 +558,7 @@ static void explore_order(const std::vector<u32>& ids, const std::vector<const u
     // per read id: where its list is, how long, whether candidates of the reciprocal pass hang on it -- one 16-byte record, one cache line per visit
     struct PL { const u32* p; u32 n; u32 cand; };
     std::vector<PL> pl(N + 2, PL{nullptr, 0, 0});
-    for (size_t w = 0; w < n; w++) pl[ids[w]] = PL{lists[w], lenp[w], hasCand[w]};
+    for (size_t w = 0; w < n; w++) pl[ids[w]] = PL{lists[w], lenp[w], (u32)hasCand[w] | 2u};     // bit 1: an unresolved read (a start of the outer loop, :513)
     // by read id: 0 = unexplored (status 0), else the 1-based exploration order, bit 31 = marked (status 2, :679) -- one table, one look-up
     rank.assign(N + 2, 0);
     constexpr u32 MARK = 0x80000000u, RK = 0x7FFFFFFFu;
@@ -566,7 +566,6 @@ static void explore_order(const std::vector<u32>& ids, const std::vector<const u
     constexpr u32 IDM = 0x3FFFFFFFu;                                             // entry = to | kind << 30: 0 both sides see each other, 1 own hit only, 2 twin only
     // an own-only hit is in the list iff its target was explored later (or not yet), a twin-only one iff its source was explored earlier
     auto present = [&](u32 rw, u32 e) -> bool { const u32 k = e >> 30; if (k == 0) return true; const u32 rt = rank[e & IDM] & RK; return k == 1 ? (rt == 0 || rt > rw) : (rt != 0 && rt < rw); };
-    std::vector<u32> order(ids.begin(), ids.end()); std::sort(order.begin(), order.end());
     std::vector<u32> queue;
     auto explore_neighbours = [&](u32 r) {                                       // every still unexplored neighbour this read sees, in list order (:531-541)
         const u32* plist = pl[r].p;
@@ -576,14 +575,14 @@ static void explore_order(const std::vector<u32>& ids, const std::vector<const u
             const u32 to = e & IDM; if (rank[to] == 0) { rank[to] = ++ctr; queue.push_back(to); }
         }
     };
-    for (u32 id0 : order) {
-        if (rank[id0] != 0) continue;
+    for (u32 id0 = 1; id0 <= (u32)N; id0++) {                                    // ascending ids, as the serial loop starts its searches
+        if (!(pl[id0].cand & 2u) || rank[id0] != 0) continue;
         queue.clear(); size_t start = 0; queue.push_back(id0);
         while (start < queue.size()) {
             const u32 r1 = queue[start++];
             if (rank[r1] == 0) rank[r1] = ++ctr;
             const u32 rw = rank[r1] & RK, b1 = 0, e1 = pl[r1].n; const u32* plist = pl[r1].p;
-            bool any = pl[r1].cand != 0;
+            bool any = (pl[r1].cand & 1u) != 0;
             for (u32 x = b1; !any && x < e1; x++) any = present(rw, plist[x]);
             if (!any) continue;                                                  // an empty list (:527)
             if (!(rank[r1] & MARK)) { explore_neighbours(r1); rank[r1] |= MARK; }
