@@ -125,7 +125,9 @@ typedef struct sage2ov_overlap_stats {
 /* buildInitialOverlapGraph (economyGraph.cpp:37): probe+verify+extension kernel over this rank's read
  * range, then the reciprocal pass (economyGraph.cpp:455-480). */
 int sage2ov_overlap_initial(sage2ov_ctx* ctx);
-/* buildOverlapGraphEconomy (economyGraph.cpp:495): all-edges + transitive reduction of unresolved reads. */
+/* buildOverlapGraphEconomy (economyGraph.cpp:495): all-edges + transitive reduction of unresolved reads.
+ * On the device; when the index hides keys (>= 100 entries, hashTable.cpp:111-123) the order in which the serial BFS explores
+ * the reads decides which edges exist (:605) and is walked on the host over device-built lists. */
 int sage2ov_overlap_reduce(sage2ov_ctx* ctx);
 /* sortEconomyGraph (economyGraph.cpp:896) + OverlapGraph::convertGraph (overlapGraph.cpp:84):
  * canonical edge list, ascending (from,to,type,length), from<to, one per (from,to,type). */
