@@ -1,0 +1,25 @@
+"""diagnostic: random data-set shapes through steps 1-3 on the device against the CPU oracle: per-read extension records, connections,
+edge list, counters"""
+import os, sys
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
+import numpy as np, fixtures as fx, sage2_amd as s2, oracle_lib as ol
+n0, n1 = int(sys.argv[1]) if len(sys.argv) > 1 else 0, int(sys.argv[2]) if len(sys.argv) > 2 else 30
+bad = 0
+for seed in range(n0, n1):
+    r = np.random.default_rng(seed)
+    L = int(r.choice([60, 100, 123, 124, 150, 160, 161, 200, 250, 251, 252, 300])); k = int(r.choice([16, 21, 31, 40, 55, 64, 70]))
+    if k >= L - 5: k = max(16, L // 2)
+    pd = dict(seed=5000 + seed, genome_len=int(r.integers(20000, 120000)), n_reads=int(r.integers(14000, 40000)), read_len=L, err_ppm=int(r.choice([0, 300, 1500, 5000])),
+              n_repeat_families=int(r.integers(0, 5)), repeat_copies=int(r.integers(20, 300)), repeat_len=int(r.integers(100, 500)))
+    if r.random() < 0.35: pd["read_len_min"] = max(k + 2, L - int(r.integers(5, 60)))
+    bases, off = fx.make_reads(pd)
+    g = s2.Context(k); g.reads_add_ascii(bases, off); g.reads_organize(); g.run_steps23()
+    o = ol.Oracle(k, 16); o.add_reads_ascii(bases, off); o.organize(); o.run_all()
+    gr, gl, gs, gc = g.overlap_export_initial(); orr, orl, ors, orc = o.export_initial()
+    e, oe = g.edges(), o.export_edges(); st = g.overlap_stats()
+    ok = np.array_equal(gc, orc) and np.array_equal(gr[1:], orr[1:]) and np.array_equal(gl[1:], orl[1:]) and len(e) == len(oe) and np.array_equal(e["from"], oe[:, 0]) \
+        and np.array_equal(e["to"], oe[:, 1]) and np.array_equal(e["type"], oe[:, 2]) and np.array_equal(e["length"], oe[:, 3]) and np.array_equal(e["length_twin"], oe[:, 4]) \
+        and (st.edges_inserted, st.transitive_removed, st.verified_overlaps) == (o.counter("edges_inserted"), o.counter("transitive_removed"), o.counter("n_ov"))
+    if not ok: bad += 1; print("MISMATCH seed", seed, pd, "k", k, flush=True)
+    g.close(); o.close()
+print("data sets", n1 - n0, "mismatches", bad, flush=True)
