@@ -203,7 +203,7 @@ class _Hip:
         self.bufs = []
 
 
-@pytest.mark.parametrize("name,world", [("g2_clean150_k40", 2), ("g5_mixedlen_k21", 3), ("g3_noisy_rep_k21", 2)])
+@pytest.mark.parametrize("name,world", [("g2_clean150_k40", 2), ("g5_mixedlen_k21", 3), ("g3_noisy_rep_k21", 2), ("g4_highcopy_k21", 2)])
 def test_sharded_contexts_on_one_gpu_match_reference(name, world, tmp_path):
     """The multi-GPU path without a cluster (SURVEY section 4): `world` rank contexts on ONE GPU, the collectives
     replaced by explicit concatenation / element-wise max of the very buffers the C ABI exports and imports.
