@@ -310,8 +310,9 @@ def main():
         }
         def step4_of(c):
             """step 4 on the graph the timed steps left in HBM: outside the timed region, two runs, the second reported"""
-            c.graph_simplify(); t4 = time.perf_counter(); c.graph_simplify(); w4 = time.perf_counter() - t4; s4 = c.simplify_stats()
-            return {"device_ms": s4.device_ms, "wall_ms": 1e3 * w4, "nodes_contracted": s4.nodes_contracted, "removed": s4.removed, "loop_iterations": s4.loop_iterations,
+            t4 = time.perf_counter(); c.graph_simplify(); w41 = time.perf_counter() - t4
+            t4 = time.perf_counter(); c.graph_simplify(); w4 = time.perf_counter() - t4; s4 = c.simplify_stats()     # (the second call first frees the first one's result)
+            return {"device_ms": s4.device_ms, "wall_ms_first_call": 1e3 * w41, "wall_ms": 1e3 * w4, "nodes_contracted": s4.nodes_contracted, "removed": s4.removed, "loop_iterations": s4.loop_iterations,
                     "edges_left": s4.edges, "reads_on_edges": s4.reads_on_edges}
         if world == 1 and not args.no_step4:
             res["step4"] = step4_of(ctx)
