@@ -1079,7 +1079,8 @@ int dev_simplify(Device* d, SimplifiedGraph& out, std::string& err) {
         hipLaunchKernelGGL(k_s4_count, gN, b256, 0, st, N, in, dctr);
         if (nh) hipLaunchKernelGGL(k_s4_dead_apply, dim3(grid_for(nh, 256)), b256, 0, st, g, nh, in);
         u32 v = 0; if (rd(&v, 1)) { err = "step 4: counter read failed"; return SAGE2OV_ERR_DEVICE; }
-        *removed = v; if (v) adjValid = false; return 0;
+        *removed = v; if (v) hipLaunchKernelGGL(k_s4_filteradj, gN, b256, 0, st, g, N);     // deletions only: the lists are compacted, not rebuilt
+        return 0;
     };
     // ---- removeBubbles (simplification.cpp:118-194)
     auto bubbles = [&](long long closeLength, u64* removed) -> int {
@@ -1100,7 +1101,8 @@ int dev_simplify(Device* d, SimplifiedGraph& out, std::string& err) {
         hipLaunchKernelGGL(k_s4_count, gN, b256, 0, st, N, din, dctr);
         if (nh) hipLaunchKernelGGL(k_s4_bubble_apply, dim3(grid_for(nh, 256)), b256, 0, st, g, nh, rin);
         u32 v = 0; if (rd(&v, 1)) { err = "step 4: counter read failed"; return SAGE2OV_ERR_DEVICE; }
-        *removed = v; if (v) adjValid = false; return 0;
+        *removed = v; if (v) hipLaunchKernelGGL(k_s4_filteradj, gN, b256, 0, st, g, N);
+        return 0;
     };
     // ---- main.cpp:150-172
     int threshold = 0; long long closeValue = 10; u64 contracted = 0, removed = 0, iters = 0, x = 0;
