@@ -31,6 +31,9 @@ FIXTURES = {
                                       n_repeat_families=1, repeat_copies=500, repeat_len=150)),
     "g5_mixedlen_k21":   (21, 1, dict(seed=5, genome_len=40000, n_reads=24000, read_len=100, read_len_min=70, err_ppm=2000)),
     "g6_k70_150":        (70, 8, dict(seed=6, genome_len=60000, n_reads=20000, read_len=150, err_ppm=1000)),
+    # 250-bp reads with errors and a few repeats: 8-word slots with bases and length sharing the last dword, 16-dword compares
+    "g8_noisy250_k45":   (45, 8, dict(seed=8, genome_len=90000, n_reads=18000, read_len=250, err_ppm=1500,
+                                      n_repeat_families=2, repeat_copies=6, repeat_len=400)),
     # hand-made input (tests/fixtures.py::recipe_reads): palindromic region, tandem repeat, mirrored duplicates
     "g7_palindrome_tandem_k21": (21, 8, dict(recipe="palindrome_tandem", seed=7, half=700, flank=24000, tandem_units=60, read_len=100, step=3)),
 }
