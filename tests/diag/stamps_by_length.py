@@ -1,5 +1,6 @@
+"""diagnostic: run with a -DSAGE2OV_STAMPS build (SAGE2OV_LIB=...): share of wave cycles per stage of the probe kernel, 100- and 150-bp reads"""
 import os, sys
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 import fixtures as fx, sage2_amd as s2
 n = 2_000_000
 for L in (100, 150):
