@@ -11,6 +11,9 @@
 #include <cstring>
 #include <parallel/algorithm>
 #include <string>
+#include <thread>
+#include <mutex>
+#include <condition_variable>
 #include <unordered_map>
 #include <vector>
 #include <omp.h>
@@ -120,10 +123,36 @@ struct CodeInit { CodeInit() { memset(g_code, 255, 256); g_code['A'] = g_code['a
 // minimal FASTA/FASTQ(.gz) record reader with kseq-like rules (fastAQReader.cpp:16-45)
 struct SeqFile {
     gzFile fp = nullptr; std::vector<char> buf; size_t pos = 0, end = 0; bool eof = false; const char* win = nullptr;   // win: the current window (buf, or a mapped range)
-    bool open(const char* p) { fp = gzopen(p, "r"); if (fp) gzbuffer(fp, 1 << 20); buf.resize(8 << 20); win = buf.data(); return fp != nullptr; }
+    // gzip inflates at a few hundred MB/s on one thread: a reader thread fills the next 8 MB window while the caller splits the current one
+    std::vector<char> nextBuf; std::thread reader; std::mutex mu; std::condition_variable cv; int nextN = 0; bool nextReady = false, wantNext = false, quit = false;
+    void reader_loop() {
+        for (;;) {
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return wantNext || quit; }); if (quit) return; wantNext = false; }
+            const int n = gzread(fp, nextBuf.data(), (unsigned)nextBuf.size());
+            { std::lock_guard<std::mutex> lk(mu); nextN = n; nextReady = true; }
+            cv.notify_all();
+            if (n <= 0) return;
+        }
+    }
+    bool open(const char* p) {
+        fp = gzopen(p, "r"); if (!fp) return false;
+        gzbuffer(fp, 1 << 20); buf.resize(8 << 20); nextBuf.resize(8 << 20); win = buf.data();
+        wantNext = true; reader = std::thread([this] { reader_loop(); });
+        return true;
+    }
     void open_range(const char* b, size_t n) { win = b; pos = 0; end = n; eof = true; }        // parse a range of a mapped file: one window, never refilled
-    ~SeqFile() { if (fp) gzclose(fp); }
-    bool refill() { if (eof) return false; int n = gzread(fp, buf.data(), (unsigned)buf.size()); if (n <= 0) { eof = true; return false; } end = (size_t)n; pos = 0; return true; }
+    ~SeqFile() {
+        if (reader.joinable()) { { std::lock_guard<std::mutex> lk(mu); quit = true; } cv.notify_all(); reader.join(); }
+        if (fp) gzclose(fp);
+    }
+    bool refill() {
+        if (eof) return false;
+        int n;
+        { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return nextReady; }); n = nextN; nextReady = false; if (n > 0) { buf.swap(nextBuf); wantNext = true; } }
+        if (n <= 0) { eof = true; return false; }
+        cv.notify_all();
+        win = buf.data(); end = (size_t)n; pos = 0; return true;
+    }
     // next line (without the line end) appended to `s`; lines are found with memchr on the 8 MB window
     bool line(std::string& s) {
         s.clear(); bool any = false;
