@@ -167,8 +167,34 @@ struct SeqFile {
         return any;
     }
     std::string held, l; bool haveHeld = false;
+    // The common shapes -- a FASTA record with one sequence line, a four-line FASTQ record -- when the whole record and the first
+    // character behind it lie inside the current window: found with memchr, the sequence copied once, no per-line strings.
+    // Anything else (multi-line sequences, white space inside a line, a record that crosses the window) is left to the general path.
+    bool fast_next(std::string& out, size_t& len) {
+        if (haveHeld || pos >= end) return false;
+        const char* const b = win + pos; const char* const e = win + end;
+        const char kind = *b; if (kind != '>' && kind != '@') return false;
+        const char* nl1 = (const char*)memchr(b, '\n', (size_t)(e - b)); if (!nl1) return false;
+        const char* sq = nl1 + 1; const char* nl2 = (const char*)memchr(sq, '\n', (size_t)(e - sq)); if (!nl2 || nl2 + 1 >= e) return false;
+        size_t n = (size_t)(nl2 - sq); if (n && sq[n - 1] == '\r') n--;
+        if (n == 0) return false;
+        for (size_t i = 0; i < n; i++) if ((unsigned char)sq[i] <= ' ') return false;
+        const char* after = nl2 + 1;
+        if (kind == '>') { if (*after != '>') return false; }
+        else {
+            if (*after != '+') return false;
+            const char* nl3 = (const char*)memchr(after, '\n', (size_t)(e - after)); if (!nl3) return false;
+            const char* q = nl3 + 1; const char* nl4 = (const char*)memchr(q, '\n', (size_t)(e - q)); if (!nl4 || nl4 + 1 >= e) return false;
+            size_t nq = (size_t)(nl4 - q); if (nq && q[nq - 1] == '\r') nq--;
+            if (nq != n || nl4[1] != '@') return false;
+            after = nl4 + 1;
+        }
+        out.append(sq, n); len = n; pos = (size_t)(after - win);
+        return true;
+    }
     // bases of the next record appended to `out` (white space dropped); false at end of file
     bool next(std::string& out, size_t& len) {
+        if (fast_next(out, len)) return true;
         const size_t start = out.size();
         for (;;) { if (haveHeld) { l.swap(held); haveHeld = false; } else if (!line(l)) return false; if (!l.empty() && (l[0] == '>' || l[0] == '@')) break; }
         for (;;) {
