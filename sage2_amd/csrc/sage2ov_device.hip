@@ -432,7 +432,7 @@ __global__ void k_pack_records(u64 lo, u64 hi, const u64* right, const u64* left
 __global__ void k_unpack_records(u64 first, u64 n, const Record* in, u64* right, u64* left, u32* conn, u32* cflag, bool own) {
     u64 x = (u64)blockIdx.x * blockDim.x + threadIdx.x; if (x >= n) return;
     Record r = in[x]; u64 i = first + x; right[i] = r.right; left[i] = r.left; conn[i] = r.conn;
-    (void)own; cflag[i] = r.cflag;
+    (void)own; cflag[i] |= r.cflag;       // containment marks (economyGraph.cpp:735) are OR-ed, never overwritten: the local probe may have marked read i too
 }
 // containment flags travel as two byte planes (bit0 plane, bit1 plane) so that a MAX all-reduce is a bitwise OR
 __global__ void k_flags_export(u64 n, const u32* __restrict__ cflag, uint8_t* out) {
@@ -754,10 +754,10 @@ int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved
         const u32 nhv = (u32)c[0];
         WS(hsize, u32, WS_RA_HSIZE, nhv); WS(hscr, u64, WS_RA_HSCR, nhv);
         hipLaunchKernelGGL(k_ra_heavy_sizes, dim3(grid_for(nhv, 256)), dim3(256), 0, d->stream, heavy, nhv, ids, deg, hsize);
-        std::vector<u32> hs(nhv); HIPCHK(hipMemcpy(hs.data(), hsize, nhv * sizeof(u32), hipMemcpyDeviceToHost));
+        std::vector<u32> hs(nhv); HIPCHK(hipMemcpyAsync(hs.data(), hsize, nhv * sizeof(u32), hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));   // (the stream is non-blocking: the null stream does not wait for it)
         std::vector<u64> so(nhv); u64 words = 0;
         for (u32 b = 0; b < nhv; b++) { u64 P = 64; while (P < hs[b]) P <<= 1; so[b] = words; words += P + 2 * P + 2 * P; }      // key[P] u64 + ht[4P] u32 + mk[4P] u32
-        HIPCHK(hipMemcpy(hscr, so.data(), nhv * sizeof(u64), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpyAsync(hscr, so.data(), nhv * sizeof(u64), hipMemcpyHostToDevice, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
         u64* scratch = nullptr; HIPCHK(hipMalloc(&scratch, words * sizeof(u64)));
         hipLaunchKernelGGL(k_ra_mark_big, dim3(nhv), dim3(64), 0, d->stream, ids, heavy, hscr, scratch, offs, deg, ent, rm, svn, d->d_counters + 8);
         hipError_t e2 = hipStreamSynchronize(d->stream); hipFree(scratch);
@@ -837,8 +837,9 @@ int dev_debug_keys(Device* d, uint64_t* out, std::string& err) {
 int dev_debug_all_hits(Device* d, std::vector<Hit>& hits, std::string& err) {
     HIPCHK(hipSetDevice(d->ordinal));
     const u64 N = d->N; uint8_t* saved = nullptr;
-    HIPCHK(hipMalloc(&saved, N + 1)); HIPCHK(hipMemcpy(saved, d->status, N + 1, hipMemcpyDeviceToDevice));
-    HIPCHK(hipMemset(d->status, 0, N + 1));
+    HIPCHK(hipMalloc(&saved, N + 1)); HIPCHK(hipStreamSynchronize(d->stream));
+    HIPCHK(hipMemcpyAsync(saved, d->status, N + 1, hipMemcpyDeviceToDevice, d->stream));
+    HIPCHK(hipMemsetAsync(d->status, 0, N + 1, d->stream));
     u64 cap = std::max<u64>(1 << 16, N * 128); Hit* dh = nullptr;
     HIPCHK(hipMalloc(&dh, cap * sizeof(Hit)));
     HIPCHK(hipMemsetAsync(d->d_counters + 4, 0, sizeof(u64), d->stream));
@@ -848,7 +849,7 @@ int dev_debug_all_hits(Device* d, std::vector<Hit>& hits, std::string& err) {
     if (!rc) { HIPCHK(hipMemcpyAsync(&nh, d->d_counters + 4, sizeof nh, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream)); }
     if (!rc && nh > cap) { err = "debug hit buffer too small"; rc = SAGE2OV_ERR_LIMIT; }
     if (!rc) { hits.resize(nh); if (nh) HIPCHK(hipMemcpy(hits.data(), dh, nh * sizeof(Hit), hipMemcpyDeviceToHost)); }
-    HIPCHK(hipMemcpy(d->status, saved, N + 1, hipMemcpyDeviceToDevice));
+    HIPCHK(hipMemcpyAsync(d->status, saved, N + 1, hipMemcpyDeviceToDevice, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
     hipFree(saved); hipFree(dh);
     return rc;
 }
@@ -859,10 +860,10 @@ int dev_append_edges(Device* d, const EdgeCand* e, uint64_t n, std::string& err)
     if (d->n_cand + n > d->cand_cap) {
         EdgeCand* nc = nullptr; u64 ncap = d->n_cand + n + 1024;
         HIPCHK(hipMalloc(&nc, ncap * sizeof(EdgeCand)));
-        HIPCHK(hipMemcpy(nc, d->cand, d->n_cand * sizeof(EdgeCand), hipMemcpyDeviceToDevice));
+        HIPCHK(hipMemcpyAsync(nc, d->cand, d->n_cand * sizeof(EdgeCand), hipMemcpyDeviceToDevice, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
         hipFree(d->cand); d->cand = nc; d->cand_cap = ncap;
     }
-    HIPCHK(hipMemcpy(d->cand + d->n_cand, e, n * sizeof(EdgeCand), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpyAsync(d->cand + d->n_cand, e, n * sizeof(EdgeCand), hipMemcpyHostToDevice, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
     d->n_cand += n;
     return 0;
 }

@@ -122,7 +122,7 @@ struct CodeInit { CodeInit() { memset(g_code, 255, 256); g_code['A'] = g_code['a
 
 // minimal FASTA/FASTQ(.gz) record reader with kseq-like rules (fastAQReader.cpp:16-45)
 struct SeqFile {
-    gzFile fp = nullptr; std::vector<char> buf; size_t pos = 0, end = 0; bool eof = false; const char* win = nullptr;   // win: the current window (buf, or a mapped range)
+    gzFile fp = nullptr; std::vector<char> buf; size_t pos = 0, end = 0; bool eof = false, ioError = false; const char* win = nullptr;   // win: the current window (buf, or a mapped range)
     // gzip inflates at a few hundred MB/s on one thread: a reader thread fills the next 8 MB window while the caller splits the current one
     std::vector<char> nextBuf; std::thread reader; std::mutex mu; std::condition_variable cv; int nextN = 0; bool nextReady = false, wantNext = false, quit = false;
     void reader_loop() {
@@ -149,7 +149,7 @@ struct SeqFile {
         if (eof) return false;
         int n;
         { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return nextReady; }); n = nextN; nextReady = false; if (n > 0) { buf.swap(nextBuf); wantNext = true; } }
-        if (n <= 0) { eof = true; return false; }
+        if (n <= 0) { eof = true; if (n < 0) ioError = true; return false; }      // n < 0: corrupt or truncated gzip stream (gzerror), not an end of file
         cv.notify_all();
         win = buf.data(); end = (size_t)n; pos = 0; return true;
     }
@@ -323,6 +323,10 @@ int add_files(sage2ov_ctx* c, const char* p1, const char* p2) {
             c->goodReads += good[t]; c->totalBP += bp[t]; c->smallReads += small[t];
         }
         c->totalReads += (uint64_t)nb;
+    }
+    for (SeqFile* f : {&f1, &f2}) if (f->ioError) {
+        int en = 0; const char* m = f->fp ? gzerror(f->fp, &en) : nullptr;
+        return c->fail(SAGE2OV_ERR_IO, std::string("read error in ") + (f == &f1 ? p1 : p2) + ": " + (m && *m ? m : "corrupt or truncated input"));
     }
     return SAGE2OV_OK;
 }
@@ -573,7 +577,7 @@ static int choose_S(int maxL) { int need = (2 * maxL + 9 + 63) / 64; int S = 4; 
 int sage2ov_reads_organize(sage2ov_ctx* c) {                                          // readLoader.cpp:215-260
     if (!c) return SAGE2OV_ERR_ARG;
     if (c->organized) return c->fail(SAGE2OV_ERR_ARG, "reads already organised");
-    omp_set_num_threads(io_threads(c));
+    const int nthr = io_threads(c);                                                   // (clauses, not omp_set_num_threads: a library call must not change the host's OpenMP state)
     const uint64_t n = c->poolLen.size();
     int maxL = 0; for (uint64_t i = 0; i < n; i++) maxL = std::max<int>(maxL, c->poolLen[i]);
     c->maxL = maxL; c->S = choose_S(std::max(maxL, 1));
@@ -587,16 +591,16 @@ int sage2ov_reads_organize(sage2ov_ctx* c) {                                    
                                     &N, c->words, c->freq, c->err);
         if (rc) return rc;
         c->N = N; c->len.assign(N + 1, 0);
-        #pragma omp parallel for
+        #pragma omp parallel for num_threads(nthr)
         for (uint64_t i = 1; i <= N; i++) c->len[i] = (uint16_t)(c->words[i * c->S + c->S - 1] & SLOT_LEN_MASK);
         std::vector<uint64_t>().swap(c->pool); std::vector<uint64_t>().swap(c->poolOff); std::vector<uint16_t>().swap(c->poolLen);
         c->organized = true; c->indexBuilt = c->probed = c->reciprocalDone = c->reduced = c->converted = false;
         return SAGE2OV_OK;
     }
-    #pragma omp parallel for
+    #pragma omp parallel for num_threads(nthr)
     for (uint64_t i = 0; i < n; i++) canonicalise_words(&c->pool[c->poolOff[i]], c->poolLen[i]);
     std::vector<uint32_t> ord(n);
-    #pragma omp parallel for
+    #pragma omp parallel for num_threads(nthr)
     for (uint64_t i = 0; i < n; i++) ord[i] = (uint32_t)i;
     const uint64_t* pool = c->pool.data(); const uint64_t* off = c->poolOff.data(); const uint16_t* pl = c->poolLen.data();
     auto cmp = [&](uint32_t a, uint32_t b) -> int {                                   // utils.cpp:224-242 on big-endian words
@@ -612,7 +616,7 @@ int sage2ov_reads_organize(sage2ov_ctx* c) {                                    
         }
         return 0;
     };
-    __gnu_parallel::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return cmp(a, b) < 0; });   // readLoader.cpp:221
+    __gnu_parallel::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return cmp(a, b) < 0; }, __gnu_parallel::default_parallel_tag(nthr));   // readLoader.cpp:221
     // unique + frequency (readLoader.cpp:225-235)
     std::vector<uint32_t> firstOf; firstOf.reserve(n); std::vector<uint16_t> fr; fr.reserve(n);
     for (uint64_t x = 0; x < n; x++) {
@@ -621,7 +625,7 @@ int sage2ov_reads_organize(sage2ov_ctx* c) {                                    
     }
     const uint64_t N = firstOf.size(); const int S = c->S;
     c->N = N; c->words.assign((N + 1) * S, 0); c->len.assign(N + 1, 0); c->freq.assign(N + 1, 0);
-    #pragma omp parallel for
+    #pragma omp parallel for num_threads(nthr)
     for (uint64_t i = 1; i <= N; i++) {
         const uint32_t a = firstOf[i - 1]; const int L = pl[a], nw = (L + 31) / 32;
         uint64_t* w = &c->words[i * S];
@@ -779,7 +783,6 @@ int sage2ov_overlap_initial(sage2ov_ctx* c) {
 int sage2ov_overlap_reduce(sage2ov_ctx* c) {
     if (!c) return SAGE2OV_ERR_ARG; if (!c->reciprocalDone) return c->fail(SAGE2OV_ERR_ARG, "run the initial pass first");
     auto t0 = std::chrono::steady_clock::now();
-    omp_set_num_threads(io_threads(c));                          // (the parallel sort and the marks of the host replay)
     // Many unresolved reads and no long bucket: the order-independent form runs on the device; the serial
     // replay below stays the path for long-bucket indexes (A.7) and for a handful of reads.  Both are exact.
     {
@@ -805,7 +808,7 @@ int sage2ov_overlap_reduce(sage2ov_ctx* c) {
         std::vector<uint32_t> ids; rc = dev_unresolved_ids(c->dev, ids, c->err); if (rc) return rc;
         std::vector<EdgeCand> near; rc = dev_collect_reduce_edges(c->dev, near, c->err); if (rc) return rc;
         lap("ids + nearby candidates");
-        __gnu_parallel::sort(hits.begin(), hits.end(), [](const Hit& a, const Hit& b) { return a.from != b.from ? a.from < b.from : a.seq < b.seq; });
+        __gnu_parallel::sort(hits.begin(), hits.end(), [](const Hit& a, const Hit& b) { return a.from != b.from ? a.from < b.from : a.seq < b.seq; }, __gnu_parallel::default_parallel_tag(io_threads(c)));
         lap("sort hits");
         if (c->replayDense.size() != c->N + 2) c->replayDense.assign(c->N + 2, 0);
         Replay R(c->replayDense); R.c = c; R.hits = &hits;

@@ -93,13 +93,15 @@ def run_steps23_sharded(ctx, device, group=None):
     send = torch.zeros(ms * RECORD_BYTES, dtype=torch.uint8, device=device)
     _sync(send)                                   # the fill runs on torch's stream, the export on the library's
     ctx.shard_export_records(send.data_ptr(), ms)
+    # the containment marks this rank's probe placed on reads of ANY rank leave before other ranks' records come in
+    # (the import ORs the flags it carries, so the order is not load-bearing; it mirrors the C-ABI test)
+    planes = torch.zeros(ctx.shard_flags_bytes(), dtype=torch.uint8, device=device)
+    _sync(planes)
+    ctx.shard_export_flags(planes.data_ptr())
     for first, cnt, t in allgather_records(send, n, group):
         if cnt:
             t = t.contiguous()
             ctx.shard_import_records(t.data_ptr(), first, cnt)
-    planes = torch.zeros(ctx.shard_flags_bytes(), dtype=torch.uint8, device=device)
-    _sync(planes)
-    ctx.shard_export_flags(planes.data_ptr())
     allreduce_flags(planes, group)
     ctx.shard_import_flags(planes.data_ptr())
     ctx.overlap_reciprocal()
