@@ -1,0 +1,62 @@
+"""The full-size digests (tests/golden/*_digest.json, written by oracle/make_digests.py from the pinned restatement).
+CPU: the committed small digests are reproduced by the oracle here (so digest code and oracle cannot drift apart unnoticed).
+GPU (-m gpu): the HIP path, through the C ABI, must reproduce every committed digest -- including BASELINE configs[1] (10 M reads),
+its noisy variant and configs[2] (50 M reads, the north-star target) -- counters, per-read records, edge list and P.graph3."""
+import os
+
+import numpy as np
+import pytest
+
+import digests as dg
+import fixtures as fx
+import oracle_lib as ol
+import sage2_amd as s2
+
+
+@pytest.mark.parametrize("name", ["c1", "c2_1m"])
+def test_oracle_reproduces_committed_digest(name, tmp_path):
+    want = dg.load(name)
+    assert want is not None, f"tests/golden/{name}_digest.json missing: python oracle/make_digests.py {name}"
+    cfg = dg.CONFIGS[name]
+    assert want["k"] == cfg["k"] and want["synth"] == cfg["synth"]
+    bases, off = fx.make_reads(cfg["synth"])
+    o = ol.Oracle(cfg["k"], 8); o.add_reads_ascii(bases, off); o.organize(); o.run_all()
+    got = {}
+    got.update(dg.initial_digest(*o.export_initial()))
+    e = o.export_edges(); got.update(dg.edges_digest(e[:, 0], e[:, 1], e[:, 2], e[:, 3], e[:, 4]))
+    got.update(dg.reads_digest(*o.export_reads(), cfg["synth"]["read_len"]))
+    gp = str(tmp_path / "t.graph3"); o.write_graph3(gp); got.update(dg.file_digest(gp))
+    got.update(n_unique=o.counter("N"), edges_inserted=o.counter("edges_inserted"), transitive_removed=o.counter("transitive_removed"))
+    assert dg.compare(got, want) == []
+    assert want.get("reference_binary_graph3_identical") is True       # make_digests ran the reference binary on this input too
+    o.close()
+
+
+def test_digest_lookup_by_parameters():
+    name, d = dg.lookup(21, dict(seed=1, genome_len=200_000, n_reads=100_000, read_len=100, err_ppm=0))
+    assert name == "c1" and d["n_unique"] == 78701
+    assert dg.lookup(22, dict(seed=1, genome_len=200_000, n_reads=100_000, read_len=100)) == (None, None)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["c1", "c2_1m", "c2", "c2_noisy", "c3"])
+def test_gpu_reproduces_full_size_digest(name, tmp_path):
+    """BASELINE sizes the oracle cannot run inside a test: every number the restatement produced for this input (make_digests.py) must
+    come out of the device path -- n_unique, N_ov (the numerator of the headline metric), crc32 of connections / extension records /
+    status classes / packed reads / canonical edge list, the reduce counters, and the md5 of P.graph3."""
+    want = dg.load(name)
+    if want is None:
+        pytest.skip(f"tests/golden/{name}_digest.json not generated")
+    cfg = dg.CONFIGS[name]
+    p = fx.synth_params(cfg["synth"])
+    ctx = s2.Context(cfg["k"], device=0)
+    ctx.reads_add_synth(p, s2.synth_genome(p)); ctx.reads_organize(); ctx.run_steps23()
+    got = dg.gpu_digest(ctx, cfg["synth"]["read_len"], graph3_path=str(tmp_path / "t.graph3"))
+    os.remove(str(tmp_path / "t.graph3"))
+    bad = dg.compare(got, want)
+    assert bad == [], f"{name}: " + "; ".join(bad)
+    # a second pass over the resident reads (atomics-ordered build) gives the same result
+    ctx.run_steps23()
+    got2 = dg.gpu_digest(ctx, cfg["synth"]["read_len"], with_reads=False)
+    assert dg.compare(got2, want) == []
+    ctx.close()
