@@ -34,7 +34,8 @@ typedef unsigned long long u64;
 typedef unsigned int u32;
 
 enum { WS_SLOTS, WS_CNT, WS_WHERE, WS_BIG, WS_CSR, WS_SLOW, WS_NEED, WS_DEG, WS_OFFS, WS_CURSOR, WS_KEYS, WS_KEEP, WS_POS, WS_OWNER, WS_FINAL,
-       WS_PARTIAL, WS_IDS, WS_NEAR, WS_HITS, WS_MINH, WS_OCNT, WS_OOFF, WS_OCUR, WS_ORDER, WS_MI1, WS_MICNT, WS_MICUR, WS_KREC, WS_SLOTMH, WS_RA_DEG, WS_RA_OFF, WS_RA_CUR, WS_RA_ENT, WS_RA_RM, WS_ORG_POOL, WS_ORG_OFF, WS_ORG_LEN, WS_ORG_IMG, WS_ORG_K0, WS_ORG_K1, WS_ORG_V0, WS_ORG_V1, WS_ORG_HIST, WS_ORG_HSCAN, WS_ORG_FLAG, WS_ORG_UID, WS_ORG_HEAD, WS_RR_IN, WS_RR_DEGP, WS_RR_OFFP, WS_RR_ENTP, WS_RR_OUTP, WS_RR_WIDX, WS_RR_RANK, WS_RR_CUR, WS_RA_HEAVY, WS_RA_HSIZE, WS_RA_HSCR, WS_RR_LEN, WS_RR_COFF, WS_RR_OUTC, WS_COUNT };   // ids of the workspace arena (Device::ws)
+       WS_PARTIAL, WS_IDS, WS_NEAR, WS_HITS, WS_MINH, WS_OCNT, WS_OOFF, WS_OCUR, WS_ORDER, WS_MI1, WS_MICNT, WS_MICUR, WS_KREC, WS_SLOTMH, WS_RA_DEG, WS_RA_OFF, WS_RA_CUR, WS_RA_ENT, WS_RA_RM, WS_ORG_POOL, WS_ORG_OFF, WS_ORG_LEN, WS_ORG_IMG, WS_ORG_K0, WS_ORG_K1, WS_ORG_V0, WS_ORG_V1, WS_ORG_HIST, WS_ORG_HSCAN, WS_ORG_FLAG, WS_ORG_UID, WS_ORG_HEAD, WS_RR_IN, WS_RR_DEGP, WS_RR_OFFP, WS_RR_ENTP, WS_RR_OUTP, WS_RR_WIDX, WS_RR_RANK, WS_RR_CUR, WS_RA_HEAVY, WS_RA_HSIZE, WS_RA_HSCR, WS_RR_LEN, WS_RR_COFF, WS_RR_OUTC,
+       WS_PT_K0, WS_PT_K1, WS_PT_P0, WS_PT_P1, WS_PT_M0, WS_PT_M1, WS_PT_CNT, WS_PT_BASE, WS_PT_OFF, WS_PT_GOFF, WS_COUNT };   // ids of the workspace arena (Device::ws)
 struct Device {
     int ordinal = 0;
     hipStream_t stream = nullptr;
@@ -78,6 +79,7 @@ static void* ws_get(Device* d, int id, size_t bytes) {
 #include "kernels_common.inc"
 #include "kernels_order.inc"
 #include "kernels_organize.inc"
+#include "kernels_partition.inc"
 #include "kernels_index.inc"
 #include "kernels_scan.inc"
 #include "kernels_probe_seq.inc"
@@ -152,6 +154,8 @@ int dev_upload_reads(Device* d, const uint64_t* words, uint64_t N, int S, int mi
 }
 
 static int scan_u32(Device* d, const u32* in, u64 n, u32* out, u64* total, std::string& err);
+struct PtBufs { u32* K[2]; u64* P[2]; u32* M[2]; };
+static int partition_by_window(Device* d, PtBufs& B, bool hasP, bool hasM, u32 n, int shiftW, u64 nWin, bool digit0Counted, u32* cnt, u32* base, u32* off, int* cur_out, std::string& err);
 // Step 1 on the device: see k_org_canon.  On return the read store is resident exactly as after dev_upload_reads, and the
 // host receives the image (for the .reads writer, lengths) and the frequencies.
 int dev_organize_reads(Device* d, const uint64_t* pool, uint64_t pool_words, const uint64_t* off, const uint16_t* len, uint64_t n, int S, int minL, int maxL, int k,
@@ -230,68 +234,134 @@ int dev_organize_reads(Device* d, const uint64_t* pool, uint64_t pool_words, con
     return 0;
 }
 
+// exclusive scan without the read-back of the total (no host synchronisation)
+static int scan_u32_async(Device* d, const u32* in, u64 n, u32* out, std::string& err);
+
+// LSD radix passes that sort the tuples (K, optional P / M) by the window id (K >> shiftW), window ids < nWin; `digit 0 counted`
+// tells that cnt already holds the first digit's per-tile histogram (taken by the kernel that wrote the tuples).  On return
+// *Ks / *Ps / *Ms point at the sorted arrays (one of the two buffer sets) and off[0..nWin] holds the window boundaries.
+static int pt_digits(u64 nWin, int* bits, int* nd) {            // window id bits, number of <= 9-bit digits
+    int wb = 0; while ((1ull << wb) < nWin) wb++;
+    *bits = wb; *nd = wb == 0 ? 0 : (wb + 8) / 9; return 0;
+}
+static int partition_by_window(Device* d, PtBufs& B, bool hasP, bool hasM, u32 n, int shiftW, u64 nWin, bool digit0Counted, u32* cnt, u32* base, u32* off, int* cur_out, std::string& err) {
+    int wb, nd; pt_digits(nWin, &wb, &nd);
+    const u32 ntiles = (u32)((n + PT_TILE - 1) / PT_TILE);
+    int cur = 0;
+    if (n) {
+        const int bper = nd ? (wb + nd - 1) / nd : 0;
+        for (int j = 0; j < nd; j++) {
+            const int shift = shiftW + j * bper; const int bj = std::min(bper, wb - j * bper); const u32 mask = (1u << bj) - 1u;
+            if (!(j == 0 && digit0Counted)) hipLaunchKernelGGL(k_pt_hist, dim3(ntiles), dim3(PT_THREADS), 0, d->stream, B.K[cur], n, shift, mask, cnt, ntiles);
+            int rc = scan_u32_async(d, cnt, (u64)(mask + 1) * ntiles, base, err); if (rc) return rc;
+            const int o = cur ^ 1;
+            if (hasP && hasM) hipLaunchKernelGGL((k_pt_scatter<true, true>), dim3(ntiles), dim3(PT_THREADS), 0, d->stream, B.K[cur], B.P[cur], B.M[cur], n, shift, mask, base, ntiles, B.K[o], B.P[o], B.M[o]);
+            else if (hasP) hipLaunchKernelGGL((k_pt_scatter<true, false>), dim3(ntiles), dim3(PT_THREADS), 0, d->stream, B.K[cur], B.P[cur], (const u32*)nullptr, n, shift, mask, base, ntiles, B.K[o], B.P[o], (u32*)nullptr);
+            else hipLaunchKernelGGL((k_pt_scatter<false, true>), dim3(ntiles), dim3(PT_THREADS), 0, d->stream, B.K[cur], (const u64*)nullptr, B.M[cur], n, shift, mask, base, ntiles, B.K[o], (u64*)nullptr, B.M[o]);
+            cur = o;
+        }
+        if (off) hipLaunchKernelGGL(k_pt_bounds, dim3(grid_for(n, 256)), dim3(256), 0, d->stream, B.K[cur], n, shiftW, (u32)nWin, off);
+    } else if (off) HIPCHK(hipMemsetAsync(off, 0, (nWin + 1) * sizeof(u32), d->stream));
+    HIPCHK(hipGetLastError());
+    *cur_out = cur;
+    return 0;
+}
+// first-digit parameters of the tuple kernel (must agree with partition_by_window)
+static void pt_first_digit(u64 nWin, int shiftW, int* shift0, u32* mask0, int* doHist) {
+    int wb, nd; pt_digits(nWin, &wb, &nd);
+    if (!nd) { *shift0 = 0; *mask0 = 0; *doHist = 0; return; }
+    const int bper = (wb + nd - 1) / nd; *shift0 = shiftW; *mask0 = (1u << std::min(bper, wb)) - 1u; *doHist = 1;
+}
+
 int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t* csr_out, uint64_t* nlong_out, uint32_t* rebuilds, std::string& err) {
     HIPCHK(hipSetDevice(d->ordinal));
     const u64 N = d->N; if (!d->reads) { err = "reads not resident"; return SAGE2OV_ERR_ARG; }
-    d->T = std::max<u64>(1024, 8 * N);                                   // load <= 0.5, as hashTable.cpp:83 sizes it (even: pairs)
+    d->T = std::max<u64>(IX_W, (8 * N + IX_W - 1) / IX_W * IX_W);            // load <= 0.5, as hashTable.cpp:83 sizes it; whole windows
     if (d->T >= (1ull << 32)) { err = "table too large for 32-bit slot indices"; return SAGE2OV_ERR_LIMIT; }
+    const u64 nW = d->T / IX_W; const u32 n = (u32)(4 * N);
     const u32 big_cap = 1u << 20;
     WS(slots_ws, u64, WS_SLOTS, d->T); d->slots = slots_ws;
-    WS(where, u64, WS_WHERE, std::max<u64>(1, 4 * N));               // per entry: slot index | rank inside the bucket << 32
     WS(big, u64, WS_BIG, (u64)big_cap * 3);
     WS(csr_ws, u32, WS_CSR, std::max<u64>(1, 4 * N)); d->csr = csr_ws;
     const bool wantMI = !getenv("SAGE2OV_NO_MINIMIZER_INDEX") && (d->h - std::min(d->h, 16) + 1) >= 8;
-    u64* slot_g = nullptr; u64* mi1 = nullptr; u64* krec = nullptr; u64 TL = 0;
+    u64 TL = 0; int tlBits = 0; u64 gW = 0;
+    if (wantMI) { TL = IX_GW; tlBits = IX_GWLOG; while (TL < d->T / 4) { TL <<= 1; tlBits++; } gW = TL / IX_GW; }   // >= 2N group words
+    const u64 nAlloc = std::max<u64>(4, (u64)n + 4);
+    const u32 ntiles = (u32)((n + PT_TILE - 1) / PT_TILE);
+    PtBufs B;
+    { WS(a, u32, WS_PT_K0, nAlloc); B.K[0] = a; } { WS(a, u32, WS_PT_K1, nAlloc); B.K[1] = a; }
+    { WS(a, u64, WS_PT_P0, nAlloc); B.P[0] = a; } { WS(a, u64, WS_PT_P1, nAlloc); B.P[1] = a; }
+    { WS(a, u32, WS_PT_M0, nAlloc); B.M[0] = a; } { WS(a, u32, WS_PT_M1, nAlloc); B.M[1] = a; }
+    WS(cnt, u32, WS_PT_CNT, (u64)PT_NB_MAX * std::max<u32>(ntiles, 1) + 2); WS(base, u32, WS_PT_BASE, (u64)PT_NB_MAX * std::max<u32>(ntiles, 1) + 2);
+    WS(winOff, u32, WS_PT_OFF, nW + 2);
+    u64* mi1 = nullptr; u64* krec = nullptr; u32* gOff = nullptr;
     if (wantMI) {
-        TL = 1024; while (TL < d->T / 4) TL <<= 1;                           // >= 2N group slots
-        WS(smh, u64, WS_SLOTMH, std::max<u64>(1, 4 * N)); slot_g = smh;      // per entry (rank-0 entries only): group slot | rank inside the group << 32
         WS(m1, u64, WS_MI1, TL); mi1 = m1;
-        WS(kr_, u64, WS_KREC, 4 * N + MI_SCAN_PAD); krec = kr_;              // one record per distinct key (<= 4N), written by the fill kernel
+        WS(kr_, u64, WS_KREC, 4 * N + MI_SCAN_PAD); krec = kr_;              // one record per distinct key (<= 4N)
+        WS(go, u32, WS_PT_GOFF, gW + 3); gOff = go;
     }
     HIPCHK(hipEventRecord(d->ev[0], d->stream));
     *rebuilds = 0;
+    const bool timing = getenv("SAGE2OV_TIMING") != nullptr; auto tp = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) { if (!timing) return; hipStreamSynchronize(d->stream); auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[index] %-34s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - tp).count()); tp = t; };
+    u64 c[9];
     for (int attempt = 0;; attempt++) {
-        HIPCHK(hipMemsetAsync(d->slots, 0, d->T * sizeof(u64), d->stream));
         HIPCHK(hipMemsetAsync(d->d_counters + 8, 0, 9 * sizeof(u64), d->stream));
-        if (wantMI) HIPCHK(hipMemsetAsync(mi1, 0, TL * sizeof(u64), d->stream));
-        const unsigned gE = (unsigned)std::min<u64>(grid_for(4 * N, 256), 256 * 64);
-        hipLaunchKernelGGL(k_index_count, dim3(gE), dim3(256), 0, d->stream, d->reads, N, d->S, d->h, d->seed, d->slots, d->T, where,
-                           slot_g, mi1, TL, d->d_counters + 8);
-        hipLaunchKernelGGL(k_index_alloc, dim3(grid_for(d->T, ALLOC_ITEMS)), dim3(256), 0, d->stream, d->slots, d->T, d->d_counters + 8, big, big_cap);
-        if (wantMI) hipLaunchKernelGGL(k_mi_alloc, dim3(grid_for(TL, ALLOC_ITEMS)), dim3(256), 0, d->stream, mi1, TL, d->d_counters + 8);
-        hipLaunchKernelGGL(k_index_fill, dim3(gE), dim3(256), 0, d->stream, N, d->slots, where, d->csr, slot_g, mi1, krec);
-        hipLaunchKernelGGL(k_index_sort, dim3(grid_for(d->T, 256)), dim3(256), 0, d->stream, d->slots, d->T, d->csr);
-        u64 c[9];
+        // ---- tuples of the 4N entries, sorted by the window of their home slot
+        int shift0, doHist; u32 mask0; pt_first_digit(nW, IX_WPLOG, &shift0, &mask0, &doHist);
+        if (n) hipLaunchKernelGGL(k_ix_tuples, dim3(ntiles), dim3(PT_THREADS), 0, d->stream, d->reads, (u32)N, d->S, d->h, d->seed, (u32)(d->T >> 1), wantMI ? 1 : 0, shift0, mask0, doHist,
+                                  B.K[0], B.P[0], B.M[0], cnt, ntiles);
+        lap("tuples");
+        int cur = 0;
+        { int rc = partition_by_window(d, B, true, wantMI, n, IX_WPLOG, nW, doHist != 0, cnt, base, winOff, &cur, err); if (rc) return rc; }
+        lap("partition by table window");
+        // ---- the windows of the uniform table, built in LDS; group tuples into the free buffer set
+        IxWinArgs A; A.K = B.K[cur]; A.P = B.P[cur]; A.M = wantMI ? B.M[cur] : nullptr; A.winOff = winOff; A.nW = (u32)nW; A.slots = d->slots; A.csr = d->csr;
+        A.counters = d->d_counters + 8; A.big = big; A.big_cap = big_cap; A.gK = wantMI ? B.K[cur ^ 1] : nullptr; A.gP = wantMI ? B.P[cur ^ 1] : nullptr; A.wh = (u64*)B.P[cur ^ 1] ;
+        // (the scratch words of heavy windows and the group tuples share no buffer: tuples go to P[other] via gP, scratch needs its own)
+        { WS(whs, u64, WS_WHERE, nAlloc); A.wh = whs; }
+        hipLaunchKernelGGL(k_ix_window, dim3((unsigned)std::min<u64>(nW, 256ull * 6)), dim3(256), 0, d->stream, A);      // persistent: two rounds of 3 workgroups per CU, each with ONE pair of statistics atomics
+        HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(c, d->d_counters + 8, sizeof c, hipMemcpyDeviceToHost, d->stream));
         HIPCHK(hipStreamSynchronize(d->stream));
-        if (c[8]) { err = "a key occurs in more than 16 M reads"; return SAGE2OV_ERR_LIMIT; }
+        lap("table windows");
+        if (c[8]) { err = "index build: a key occurs in more than 16 M reads, or a table window overflowed"; return SAGE2OV_ERR_LIMIT; }
         if (c[2] > big_cap) { err = "too many long buckets"; return SAGE2OV_ERR_LIMIT; }
         if (c[2]) {
             hipLaunchKernelGGL(k_index_purity, dim3(grid_for(c[2] * 64, 256)), dim3(256), 0, d->stream, d->reads, d->S, d->h, big, c[2], d->csr, d->d_counters + 8);
             HIPCHK(hipMemcpyAsync(c, d->d_counters + 8, 5 * sizeof(u64), hipMemcpyDeviceToHost, d->stream));
             HIPCHK(hipStreamSynchronize(d->stream));
         }
-        if (c[3] == 0) { d->n_csr = c[0]; d->n_keys = c[1]; d->n_long = c[2]; break; }
+        if (c[3] == 0) { d->n_csr = c[0]; d->n_keys = c[1]; d->n_long = c[2];
+            // ---- stage B: the group tuples sorted by the window of their group word, the windows of the group table built in LDS
+            d->mi1 = nullptr; d->krec = nullptr; d->TL = 0; d->n_groups = 0;
+            if (wantMI && d->n_keys > 0) {
+                const u32 nG = n;                                        // one group tuple per entry tuple position; those without a record (GT_INVALID) sort behind window gW - 1
+                PtBufs G; G.K[0] = B.K[cur ^ 1]; G.K[1] = B.K[cur]; G.P[0] = B.P[cur ^ 1]; G.P[1] = B.P[cur]; G.M[0] = G.M[1] = nullptr;   // (the entry tuples are no longer needed)
+                int gcur = 0; const int gshift = 31 - (tlBits - IX_GWLOG);                                  // keys are minimiser hashes >> 1
+                { int rc = partition_by_window(d, G, true, false, nG, gshift, gW + 1, false, cnt, base, gOff, &gcur, err); if (rc) return rc; }
+                lap("partition by group window");
+                MiWinArgs MA; MA.gK = G.K[gcur]; MA.gP = G.P[gcur]; MA.gOff = gOff; MA.gW = (u32)gW; MA.tlBits = tlBits; MA.mi1 = mi1; MA.krec = krec; MA.counters = d->d_counters + 8; MA.wh = A.wh;
+                hipLaunchKernelGGL(k_mi_window, dim3((unsigned)std::min<u64>(gW, 256ull * 8)), dim3(256), 0, d->stream, MA);
+                // the probe scan may run past the last group: empty records behind ALL records
+                u64 mc[3];
+                HIPCHK(hipMemcpyAsync(mc, d->d_counters + 8 + 5, sizeof mc, hipMemcpyDeviceToHost, d->stream));
+                HIPCHK(hipStreamSynchronize(d->stream));
+                HIPCHK(hipMemsetAsync(krec + mc[0], 0, MI_SCAN_PAD * sizeof(u64), d->stream));   // (mc[0] records, at krec[0 .. mc[0]))
+                lap("group windows");
+                d->n_groups = mc[1];
+                if (getenv("SAGE2OV_VERIFY_MI")) {
+                    u64* vo = nullptr; HIPCHK(hipMalloc(&vo, 2 * sizeof(u64))); HIPCHK(hipMemsetAsync(vo, 0, 2 * sizeof(u64), d->stream));
+                    hipLaunchKernelGGL(k_mi_verify, dim3(grid_for(4 * N, 256)), dim3(256), 0, d->stream, d->reads, N, d->S, d->h, d->seed, d->slots, d->T, mi1, TL, krec, vo);
+                    u64 hv2[2]; HIPCHK(hipMemcpyAsync(hv2, vo, sizeof hv2, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream)); hipFree(vo);
+                    fprintf(stderr, "[verify-mi] %llu of %llu entries do not find their bucket in their key's group\n", (unsigned long long)hv2[0], (unsigned long long)hv2[1]);
+                }
+                if (mc[2] == 0 && mc[1] * 10 <= TL * 7) { d->mi1 = mi1; d->krec = krec; d->TL = TL; }   // else: too crowded, the fast kernel uses the uniform table
+            }
+            break;
+        }
         if (attempt >= 8) { err = "index build: tag collisions in long buckets persist after 8 reseeds"; return SAGE2OV_ERR_INTERNAL; }
         d->seed = d->seed * 0x9E3779B97F4A7C15ull + 12345; (*rebuilds)++;
-    }
-    // ---- stage B: minimiser groups over the distinct-key records
-    d->mi1 = nullptr; d->krec = nullptr; d->TL = 0;
-    if (wantMI && d->n_keys > 0) {
-        u64 mc[3];
-        HIPCHK(hipMemcpyAsync(mc, d->d_counters + 8 + 5, sizeof mc, hipMemcpyDeviceToHost, d->stream));
-        HIPCHK(hipStreamSynchronize(d->stream));
-        // the probe scan may run past the last group: empty records behind ALL records (there are a few more records than slots
-        // when different keys share a bucket: each key files its own copy)
-        HIPCHK(hipMemsetAsync(krec + mc[0], 0, MI_SCAN_PAD * sizeof(u64), d->stream));
-        d->n_groups = mc[1];
-        if (getenv("SAGE2OV_VERIFY_MI")) {
-            u64* vo = nullptr; HIPCHK(hipMalloc(&vo, 2 * sizeof(u64))); HIPCHK(hipMemsetAsync(vo, 0, 2 * sizeof(u64), d->stream));
-            hipLaunchKernelGGL(k_mi_verify, dim3(grid_for(4 * N, 256)), dim3(256), 0, d->stream, d->reads, N, d->S, d->h, d->seed, d->slots, where, mi1, TL, krec, vo);
-            u64 hv2[2]; HIPCHK(hipMemcpyAsync(hv2, vo, sizeof hv2, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream)); hipFree(vo);
-            fprintf(stderr, "[verify-mi] %llu of %llu entries do not find their bucket in their key's group\n", (unsigned long long)hv2[0], (unsigned long long)hv2[1]);
-        }
-        if (mc[2] == 0 && mc[1] * 10 <= TL * 7) { d->mi1 = mi1; d->krec = krec; d->TL = TL; }   // else: too crowded, the fast kernel uses the uniform table
     }
     HIPCHK(hipEventRecord(d->ev[1], d->stream));
     HIPCHK(hipStreamSynchronize(d->stream));
@@ -335,16 +405,17 @@ static int scan_u32(Device* d, const u32* in, u64 n, u32* out, u64* total, std::
 // processing order of ids [lo,hi): grouped by the reads' global minimiser (see k_minimizer)
 static int build_locality_order(Device* d, u64 lo, u64 hi, u32** order_out, std::string& err) {
     const u64 n = hi - lo;
-    u64 nbk = 1024; while (nbk < n / 16) nbk <<= 1;
-    int lg = 0; while ((1ull << lg) < nbk) lg++;
-    const int shift = 32 - lg;
-    WS(minh, u32, WS_MINH, n); WS(cnt, u32, WS_OCNT, nbk); WS(offs, u32, WS_OOFF, nbk); WS(cur, u32, WS_OCUR, nbk); WS(order, u32, WS_ORDER, n);
-    HIPCHK(hipMemsetAsync(cnt, 0, nbk * sizeof(u32), d->stream)); HIPCHK(hipMemsetAsync(cur, 0, nbk * sizeof(u32), d->stream));
-    hipLaunchKernelGGL(k_minimizer, dim3(grid_for(n, 256)), dim3(256), 0, d->stream, d->reads, (u64)lo, (u64)hi, d->S, minh);
-    hipLaunchKernelGGL(k_order_count, dim3(grid_for(n, 256)), dim3(256), 0, d->stream, minh, (u64)n, shift, cnt);
-    u64 tot = 0; int rc = scan_u32(d, cnt, nbk, offs, &tot, err); if (rc) return rc;
-    hipLaunchKernelGGL(k_order_fill, dim3(grid_for(n, 256)), dim3(256), 0, d->stream, minh, (u64)n, (u64)lo, shift, offs, cur, order);
-    *order_out = order;
+    // reads sorted by the top bits of their global minimiser's hash (two radix passes, kernels_partition.inc; the order inside a bucket
+    // of equal top bits is free): 18 bits or one bucket per ~16 reads, whichever is coarser
+    int lg = 10; while (lg < 18 && (1ull << lg) < n / 16) lg++;
+    const u32 ntiles = (u32)((n + PT_TILE - 1) / PT_TILE);
+    PtBufs B; B.P[0] = B.P[1] = nullptr;
+    { WS(a, u32, WS_MINH, n + 4); B.K[0] = a; } { WS(a, u32, WS_OCUR, n + 4); B.K[1] = a; }
+    { WS(a, u32, WS_ORDER, n + 4); B.M[0] = a; } { WS(a, u32, WS_OOFF, n + 4); B.M[1] = a; }
+    WS(cnt, u32, WS_PT_CNT, (u64)PT_NB_MAX * std::max<u32>(ntiles, 1) + 2); WS(base, u32, WS_PT_BASE, (u64)PT_NB_MAX * std::max<u32>(ntiles, 1) + 2);
+    hipLaunchKernelGGL(k_minimizer, dim3(grid_for(n, 256)), dim3(256), 0, d->stream, d->reads, (u64)lo, (u64)hi, d->S, B.K[0], B.M[0]);
+    int cur = 0; int rc = partition_by_window(d, B, false, true, (u32)n, 32 - lg, 1ull << lg, false, cnt, base, nullptr, &cur, err); if (rc) return rc;
+    *order_out = B.M[cur];
     return 0;
 }
 static ProbeArgs base_args(Device* d) {
@@ -876,6 +947,16 @@ static int scan_u32(Device* d, const u32* in, u64 n, u32* out, u64* total, std::
     hipLaunchKernelGGL(k_scan_final, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, d->stream, in, (u64)n, partial, out);
     HIPCHK(hipMemcpyAsync(total, partial + nb, sizeof(u64), hipMemcpyDeviceToHost, d->stream));
     HIPCHK(hipStreamSynchronize(d->stream));
+    return 0;
+}
+
+static int scan_u32_async(Device* d, const u32* in, u64 n, u32* out, std::string& err) {
+    const u64 nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    WS(partial, u64, WS_PARTIAL, nb + 1);
+    hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, d->stream, in, (u64)n, partial);
+    hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, d->stream, partial, (u64)nb, partial + nb);
+    hipLaunchKernelGGL(k_scan_final, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, d->stream, in, (u64)n, partial, out);
+    HIPCHK(hipGetLastError());
     return 0;
 }
 

@@ -12,7 +12,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
 def golden_names():
-    return sorted(os.path.basename(p)[:-5] for p in glob.glob(os.path.join(GOLDEN, "*.json")) if not p.endswith(".step4.json"))
+    return sorted(os.path.basename(p)[:-5] for p in glob.glob(os.path.join(GOLDEN, "*.json")) if not p.endswith(".step4.json") and not p.endswith("_digest.json"))
 
 
 def golden(name):
