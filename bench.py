@@ -6,8 +6,10 @@ torch.distributed.run, one rank per GPU.  One "step" = one pass of the hot path 
 index build + initial pass (probe/verify/extension + reciprocal) + reduce + sort/convert, i.e. the timed
 region T of SURVEY.md 8(d) ("packed unique reads resident in HBM" -> "canonical edge list resident").
 value = N_ov / T, N_ov = verified suffix-prefix overlaps (sum of the reference's `connections`).
-Workload at N=1: BASELINE.json configs[1] (10 M x 150 bp, k=40, 30 Mb genome, seed 2).  N>1: the same read set,
-read ids range-partitioned over the ranks (strong scaling), records/flags/edge buckets exchanged over RCCL.
+Workload at N=1: BASELINE.json configs[2], the north-star target (50 M x 150 bp, k=40, 150 Mb genome, seed 3: SURVEY 8d); configs[1]
+(10 M reads, seed 2) is timed beside it as `c2`.  N>1: the same read set (configs[3]), read ids range-partitioned over the ranks
+(strong scaling), records/flags/edge buckets exchanged over RCCL.  The result of every workload that has an oracle-generated digest
+(tests/golden/*_digest.json: N_ov, crc32 of the edge list, ...) is asserted against it before anything is printed.
 
 Adds to the JSON line: "roofline" (dominant kernel = k_probe, HIP-event timed inside the library) and
 "cpu_baseline" (the reference itself, oracle/_ref, on a bounded sample of the same workload, rank 0, N=1 only).
@@ -91,19 +93,12 @@ def cpu_baseline(args, s2, fx):
             out = dict(value=nov / T, unit="overlaps/s", cores=threads, kind="reference", sample=sample,
                        seconds=dict(index=t[2], initial=t[3], reduce=t[4], sort_convert=t[5]),
                        graph3_identical_to_gpu=bool(same))
-            # the same path on ONE thread, on a quarter of the sample at the same coverage, and all threads on that same
-            # quarter beside it: the reference's cost per overlap grows with the size of its table, so only equal samples compare
-            n1 = max(20000, n // 4)
-            pd1 = dict(seed=args.seed + 2000, genome_len=int(n1 * args.read_len / cov), n_reads=n1, read_len=args.read_len)
-            fa1 = os.path.join(tmp, "sample1.fa"); s2.synth_write_fasta(fx.synth_params(pd1), fa1)
-            c1 = s2.Context(args.k, device=0); c1.reads_add_file(fa1); c1.reads_organize(); c1.run_steps23(); nov1 = c1.overlap_stats().verified_overlaps; c1.close()
+            # the same path on ONE thread on the SAME sample: the reference's cost per overlap grows with the size of its table, so
+            # only equal samples compare -- and on this host its OpenMP loop is slower than its serial one (per-k-mer mallocs, utils.cpp:171-207)
             t1 = (C.c_double * 6)(); cc1 = (C.c_ulonglong * 3)()
-            if L.sage2ref_run_steps123(fa1.encode(), args.k, 1, None, t1, cc1) == 0:
+            if L.sage2ref_run_steps123(fa.encode(), args.k, 1, None, t1, cc1) == 0:
                 T1 = t1[2] + t1[3] + t1[4] + t1[5]
-                out["one_thread"] = dict(value=nov1 / T1, unit="overlaps/s", cores=1, sample=f"{n1} x {args.read_len} bp reads, same coverage", seconds=T1)
-                if L.sage2ref_run_steps123(fa1.encode(), args.k, threads, None, t1, cc1) == 0:
-                    Tn = t1[2] + t1[3] + t1[4] + t1[5]
-                    out["one_thread"]["all_threads_same_sample"] = dict(value=nov1 / Tn, cores=threads, seconds=Tn)
+                out["one_thread"] = dict(value=nov / T1, unit="overlaps/s", cores=1, sample="the same sample", seconds=dict(index=t1[2], initial=t1[3], reduce=t1[4], sort_convert=t1[5]))
             if hasattr(L, "sage2ref_run_step4") and ours4:
                 # step 4 of the reference on the same sample (its loaders, its loop, its writer), against our P.graph4
                 t4 = (C.c_double * 2)(); c4 = (C.c_ulonglong * 4)()
@@ -140,7 +135,7 @@ def cpu_baseline_subprocess(args):
            "--k", str(args.k), "--genome", str(args.genome), "--seed", str(args.seed), "--cpu-sample-reads", str(args.cpu_sample_reads),
            "--cpu-threads", str(args.cpu_threads)] + (["--cpu-port"] if args.cpu_port else [])
     try:
-        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
         for line in reversed(r.stdout.decode().splitlines()):
             if line.startswith("{"):
                 return json.loads(line)
@@ -156,19 +151,24 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-step4", action="store_true", help="skip the step-4 (graph simplification) figures reported beside the metric")
-    ap.add_argument("--reads", type=int, default=10_000_000)      # BASELINE.json configs[1]
+    ap.add_argument("--reads", type=int, default=50_000_000)      # BASELINE.json configs[2]: the target configuration
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--k", type=int, default=40)
-    ap.add_argument("--genome", type=int, default=30_000_000)
-    ap.add_argument("--seed", type=int, default=2)
+    ap.add_argument("--genome", type=int, default=0, help="genome length (default: 3 x reads, i.e. 50x coverage at 150 bp: SURVEY 8d)")
+    ap.add_argument("--seed", type=int, default=0, help="generator seed (default: 3 for the 50 M configuration, 2 otherwise: SURVEY 8d)")
     ap.add_argument("--err-ppm", type=int, default=0)
-    ap.add_argument("--cpu-sample-reads", type=int, default=400_000)
+    ap.add_argument("--no-c2", action="store_true", help="skip the secondary line: BASELINE.json configs[1] (10 M reads)")
+    ap.add_argument("--cpu-sample-reads", type=int, default=2_000_000)
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--cpu-port", action="store_true", help="time the CPU restatement instead of oracle/_ref")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-noisy-variant", action="store_true", help="skip the secondary line: the same workload with 0.1 %% substitution errors (SURVEY 8d)")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if not args.genome:
+        args.genome = 3 * args.reads
+    if not args.seed:
+        args.seed = 3 if args.reads == 50_000_000 else 2
 
     if args.cpu_baseline_worker:
         import fixtures as fx
@@ -262,8 +262,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ost = ctx.overlap_stats()
-    import zlib
-    edges_crc = zlib.crc32(ctx.edges().tobytes())                   # canonical edge list (from, to, type, length): same at every N
+    import digests as dg
+    ed = ctx.edges()
+    edges_crc = dg.edges_digest(ed["from"], ed["to"], ed["type"], ed["length"], ed["length_twin"])["edges_crc32"]   # canonical edge list: same at every N
+    del ed
+    # the oracle's numbers for this exact input (tests/golden/*_digest.json, oracle/make_digests.py): N, N_ov, edge count and edge-list crc32
+    dname, want = dg.lookup(args.k, pd)
+    digest_checked = None
+    if want is not None:
+        got = dict(n_unique=st.unique_reads, n_ov=ost.verified_overlaps, edges=ost.edges, edges_crc32=edges_crc)
+        bad = dg.compare(got, want, keys=list(got))
+        assert not bad, f"result differs from the oracle digest {dname}: " + "; ".join(bad)
+        digest_checked = dname
     if world > 1:
         t = torch.tensor([edges_crc], dtype=torch.int64, device=dev)
         tmin, tmax = t.clone(), t.clone()
@@ -280,11 +290,14 @@ def main():
         share = (hi - lo) / max(st.unique_reads, 1)                  # this rank's share of the probe work
         kern_ms = pk_ms / max(pk_n, 1)
         ach = a_probe * share / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
-        traffic = None
+        # memory-side bytes of the dominant kernel are NOT measured in this run: they are the PMC figure recorded under profiles/ for this
+        # workload (error-free, one GPU) -- reported with its source, null for anything else
+        traffic, traffic_src = None, None
         tj = os.path.join(ROOT, "profiles", "probe_traffic.json")
-        if os.path.exists(tj):
+        if os.path.exists(tj) and args.err_ppm == 0 and world == 1:
             try:
-                traffic = json.load(open(tj)).get(f"{args.reads}x{args.read_len}_k{args.k}", {}).get("bytes_per_launch")
+                te = json.load(open(tj)).get(f"{args.reads}x{args.read_len}_k{args.k}_seed{args.seed}", {})
+                traffic, traffic_src = te.get("bytes_per_launch"), te.get("source")
             except Exception:
                 traffic = None
         res = {
@@ -296,11 +309,12 @@ def main():
                                    f"seed {args.seed}, err {args.err_ppm} ppm ({cfg_name})",
                        "unique_reads": st.unique_reads, "verified_overlaps": ost.verified_overlaps, "edges": ost.edges, "edges_crc32": edges_crc,
                        "unresolved_reads": ost.left_to_explore, "partition": f"read-id range x{world}" if world > 1 else "single GPU",
+                       "oracle_digest_asserted": digest_checked,
                        "timed_region": "index build + initial pass + reduce + sort/convert; reads resident in HBM"},
             "phases_ms": {kph: v / args.steps for kph, v in phase.items()},
             "reads_per_s": st.unique_reads / (elapsed / args.steps),
             "roofline": {"bound": "hbm", "kernel": "k_probe_fast", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src and f"recorded: {traffic_src} (rocprofv3 PMC pass of this workload, not of this run)",
                          # memory-side bytes per launch (PMC, profiles/probe_traffic.json) over the live kernel time: what the kernel really pulls
                          "traffic_achieved": (traffic * share / (kern_ms * 1e-3) / 1e9) if (traffic and kern_ms > 0) else None,
                          "traffic_frac": (traffic * share / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and kern_ms > 0) else None,
@@ -316,40 +330,51 @@ def main():
                     "edges_left": s4.edges, "reads_on_edges": s4.reads_on_edges}
         if world == 1 and not args.no_step4:
             res["step4"] = step4_of(ctx)
-        if world == 1 and not args.no_noisy_variant and args.err_ppm == 0:
-            # secondary workload of SURVEY 8(d): the same reads with 0.1 % substitution errors (98 % of the reads then go through the
-            # reduce phase); same timed region, two steps
-            ctx.close()
-            pn = fx.synth_params(dict(pd, err_ppm=1000))
-            cn = s2.Context(args.k, device=local)
-            cn.reads_add_synth(pn, g); cn.reads_organize()
-            cn.run_steps23(); torch.cuda.synchronize()
-            tn = time.perf_counter(); nsteps = 2; phn = dict(index_ms=0.0, probe_ms=0.0, reciprocal_ms=0.0, reduce_ms=0.0, convert_ms=0.0)
+        def side_workload(spd, nsteps, with_step4=False):
+            """a secondary workload on its own context, outside the headline's timed region: one warm-up step, `nsteps` timed steps (same
+            timed region as the headline), its result asserted against the oracle digest when one is committed for these parameters"""
+            sp = fx.synth_params(spd)
+            c = s2.Context(args.k, device=local)
+            c.reads_add_synth(sp, s2.synth_genome(sp)); c.reads_organize()
+            c.run_steps23(); torch.cuda.synchronize()
+            t_ = time.perf_counter(); ph = dict(index_ms=0.0, probe_ms=0.0, reciprocal_ms=0.0, reduce_ms=0.0, convert_ms=0.0); pkm, pkn = 0.0, 0
             for _ in range(nsteps):
-                cn.run_steps23(); tmn = cn.timings()
-                for kph in phn:
-                    phn[kph] += getattr(tmn, kph)
-            torch.cuda.synchronize(); en = (time.perf_counter() - tn) / nsteps
-            on = cn.overlap_stats()
-            res["noisy_variant"] = {"err_ppm": 1000, "ms_per_step": 1e3 * en, "value": on.verified_overlaps / en, "unit": "overlaps/s", "steps": nsteps,
-                                    "unique_reads": cn.reads_stats().unique_reads, "verified_overlaps": on.verified_overlaps, "edges": on.edges,
-                                    "unresolved_reads": on.left_to_explore, "phases_ms": {kph: v / nsteps for kph, v in phn.items()}}
-            if not args.no_step4:
-                res["noisy_variant"]["step4"] = step4_of(cn)
-            cn.close()
+                c.run_steps23(); tm_ = c.timings()
+                for kph in ph:
+                    ph[kph] += getattr(tm_, kph)
+                pkm += tm_.probe_kernel_ms; pkn += tm_.probe_kernel_launches
+            torch.cuda.synchronize(); per = (time.perf_counter() - t_) / nsteps
+            o_, st_ = c.overlap_stats(), c.reads_stats()
+            e_ = c.edges(); crc_ = dg.edges_digest(e_["from"], e_["to"], e_["type"], e_["length"], e_["length_twin"])["edges_crc32"]; del e_
+            dn_, dw_ = dg.lookup(args.k, spd)
+            if dw_ is not None:
+                g_ = dict(n_unique=st_.unique_reads, n_ov=o_.verified_overlaps, edges=o_.edges, edges_crc32=crc_, edges_inserted=o_.edges_inserted, transitive_removed=o_.transitive_removed)
+                bad_ = dg.compare(g_, dw_, keys=list(g_))
+                assert not bad_, f"result differs from the oracle digest {dn_}: " + "; ".join(bad_)
+            a_tot, a_pr = algorithmic_bytes(st_.unique_reads, o_.verified_overlaps, o_.edges, spd["read_len"], args.k)
+            out = {"workload": f"{spd['n_reads']} x {spd['read_len']} bp, k={args.k}, {spd['genome_len']} bp genome, seed {spd['seed']}, err {spd.get('err_ppm', 0)} ppm"
+                               + (f", repeats {spd['n_repeat_families']} x {spd['repeat_copies']} x {spd['repeat_len']} bp" if spd.get("n_repeat_families") else ""),
+                   "ms_per_step": 1e3 * per, "value": o_.verified_overlaps / per, "unit": "overlaps/s", "steps": nsteps, "unique_reads": st_.unique_reads,
+                   "verified_overlaps": o_.verified_overlaps, "edges": o_.edges, "edges_crc32": crc_, "unresolved_reads": o_.left_to_explore, "long_buckets": c.index_stats().long_buckets,
+                   "oracle_digest_asserted": dn_, "phases_ms": {kph: v / nsteps for kph, v in ph.items()},
+                   "probe_kernel_ms": pkm / max(pkn, 1), "probe_kernel_algorithmic_frac": (a_pr / (pkm / max(pkn, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS) if pkm > 0 else None}
+            if with_step4 and not args.no_step4:
+                out["step4"] = step4_of(c)
+            c.close()
+            return out
+        side = dict(seed=2, genome_len=30_000_000, n_reads=10_000_000, read_len=args.read_len) if args.reads == 50_000_000 else dict(pd)
+        side.pop("err_ppm", None)
+        if world == 1 and args.err_ppm == 0 and (not args.no_c2 or not args.no_noisy_variant):
+            ctx.close()
+        if world == 1 and not args.no_c2 and args.err_ppm == 0 and args.reads == 50_000_000:
+            # BASELINE.json configs[1] (the configuration round 1 reported as the headline), three timed steps
+            res["c2"] = side_workload(side, 3)
+        if world == 1 and not args.no_noisy_variant and args.err_ppm == 0:
+            # secondary workload of SURVEY 8(d): configs[1] with 0.1 % substitution errors (98 % of the reads then go through the reduce phase)
+            res["noisy_variant"] = side_workload(dict(side, err_ppm=1000), 2, with_step4=True)
             # third workload: read errors AND high-copy repeats (k-mers with >= 100 copies are hidden by the index, hashTable.cpp:111-123, which
-            # makes discovery one-sided: the reduce phase then needs the exploration order from the host); one timed step
-            pr = fx.synth_params(dict(pd, err_ppm=1000, n_repeat_families=10, repeat_copies=300, repeat_len=400))
-            cr = s2.Context(args.k, device=local)
-            cr.reads_add_synth(pr, s2.synth_genome(pr)); cr.reads_organize()
-            cr.run_steps23(); torch.cuda.synchronize()
-            tr = time.perf_counter(); cr.run_steps23(); torch.cuda.synchronize(); er = time.perf_counter() - tr
-            orr = cr.overlap_stats(); tmr = cr.timings()
-            res["repeat_variant"] = {"err_ppm": 1000, "repeats": "10 families x 300 copies x 400 bp", "ms_per_step": 1e3 * er, "value": orr.verified_overlaps / er, "unit": "overlaps/s", "steps": 1,
-                                     "unique_reads": cr.reads_stats().unique_reads, "long_buckets": cr.index_stats().long_buckets, "verified_overlaps": orr.verified_overlaps,
-                                     "edges": orr.edges, "unresolved_reads": orr.left_to_explore,
-                                     "phases_ms": {kph: getattr(tmr, kph) for kph in ("index_ms", "probe_ms", "reciprocal_ms", "reduce_ms", "convert_ms")}}
-            cr.close()
+            # makes discovery one-sided: the reduce phase then needs the exploration order, DESIGN 5.5); one timed step
+            res["repeat_variant"] = side_workload(dict(side, err_ppm=1000, n_repeat_families=10, repeat_copies=300, repeat_len=400), 1)
         if world == 1 and not args.no_cpu_baseline:
             ctx.close()
             res["cpu_baseline"] = cpu_baseline_subprocess(args)
