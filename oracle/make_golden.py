@@ -34,6 +34,11 @@ FIXTURES = {
     # 250-bp reads with errors and a few repeats: 8-word slots with bases and length sharing the last dword, 16-dword compares
     "g8_noisy250_k45":   (45, 8, dict(seed=8, genome_len=90000, n_reads=18000, read_len=250, err_ppm=1500,
                                       n_repeat_families=2, repeat_copies=6, repeat_len=400)),
+    # a bigger set with several high-copy repeat families and read errors: hundreds of long buckets (hashTable.cpp:111-123), one-sided
+    # discovery, i.e. the reduce phase's result depends on the reference's serial exploration order (economyGraph.cpp:513-564) at a size
+    # where the device takes its ranked path by default.  Too big to commit as a file: md5 + size + counters only.
+    "g9_repeats160k_k40": (40, 8, dict(seed=9, genome_len=500000, n_reads=160000, read_len=150, err_ppm=1500,
+                                       n_repeat_families=6, repeat_copies=250, repeat_len=350)),
     # hand-made input (tests/fixtures.py::recipe_reads): palindromic region, tandem repeat, mirrored duplicates
     "g7_palindrome_tandem_k21": (21, 8, dict(recipe="palindrome_tandem", seed=7, half=700, flank=24000, tandem_units=60, read_len=100, step=3)),
 }
@@ -82,8 +87,11 @@ def main():
             meta = dict(name=name, k=k, ref_threads=threads, synth=pd, fasta_md5=md5(fa),
                         reads_md5=md5(reads), reads_size=os.path.getsize(reads),
                         graph3_md5=md5(g3), graph3_size=os.path.getsize(g3), counters=counters(log))
-            with open(g3, "rb") as fi, gzip.GzipFile(os.path.join(gold, name + ".graph3.gz"), "wb", mtime=0) as fo:
-                shutil.copyfileobj(fi, fo)
+            if os.path.getsize(g3) <= 4 << 20:
+                with open(g3, "rb") as fi, gzip.GzipFile(os.path.join(gold, name + ".graph3.gz"), "wb", mtime=0) as fo:
+                    shutil.copyfileobj(fi, fo)
+            else:
+                meta["graph3_file"] = "not committed (size): compare md5 and size"
             json.dump(meta, open(os.path.join(gold, name + ".json"), "w"), indent=1, sort_keys=True)
             print(name, meta["counters"], "graph3", meta["graph3_size"])
         finally:

@@ -11,8 +11,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
-def golden_names():
+def golden_names_all():
+    """every fixture the reference binary produced (oracle/make_golden.py), including the ones pinned by md5 + size only"""
     return sorted(os.path.basename(p)[:-5] for p in glob.glob(os.path.join(GOLDEN, "*.json")) if not p.endswith(".step4.json") and not p.endswith("_digest.json"))
+
+
+def golden_names():
+    """the fixtures whose P.graph3 is committed (and that have a step-4 dump)"""
+    return [n for n in golden_names_all() if os.path.exists(os.path.join(GOLDEN, n + ".graph3.gz"))]
 
 
 def golden(name):
@@ -21,6 +27,15 @@ def golden(name):
 
 def golden_graph3(name) -> bytes:
     return gzip.open(os.path.join(GOLDEN, name + ".graph3.gz"), "rb").read()
+
+
+def graph3_matches(path, name):
+    """the written P.graph3 against the reference's: byte for byte where the file is committed, md5 + size for the big fixtures"""
+    gz = os.path.join(GOLDEN, name + ".graph3.gz")
+    if os.path.exists(gz):
+        return open(path, "rb").read() == gzip.open(gz, "rb").read()
+    m = golden(name)
+    return os.path.getsize(path) == m["graph3_size"] and md5_file(path) == m["graph3_md5"]
 
 
 def md5_file(path):

@@ -26,6 +26,18 @@ def run_oracle(m, bases, off):
     return o
 
 
+def assert_equals_oracle(ctx, o):
+    """canonical edge list, reduce counters, N_ov and the per-read records of a finished context against a finished oracle"""
+    e, oe = ctx.edges(), o.export_edges()
+    assert len(e) == len(oe) and np.array_equal(e["from"], oe[:, 0]) and np.array_equal(e["to"], oe[:, 1])
+    assert np.array_equal(e["type"], oe[:, 2]) and np.array_equal(e["length"], oe[:, 3]) and np.array_equal(e["length_twin"], oe[:, 4])
+    st = ctx.overlap_stats()
+    assert (st.edges_inserted, st.transitive_removed, st.verified_overlaps) == (o.counter("edges_inserted"), o.counter("transitive_removed"), o.counter("n_ov"))
+    assert ctx.index_stats().long_buckets == o.counter("long_buckets")
+    gr, gl, gs, gc = ctx.overlap_export_initial(); orr, orl, ors, orc = o.export_initial()
+    assert np.array_equal(gc, orc) and np.array_equal(gr[1:], orr[1:]) and np.array_equal(gl[1:], orl[1:])
+
+
 @pytest.fixture(params=["default", "device", "host"])
 def reduce_path(request, monkeypatch):
     """The reduce phase has two exact implementations (device: order-independent form, taken for many unresolved reads when no
@@ -39,7 +51,7 @@ def reduce_path(request, monkeypatch):
     return request.param
 
 
-@pytest.mark.parametrize("name", fx.golden_names())
+@pytest.mark.parametrize("name", fx.golden_names_all())
 def test_files_identical_to_reference(name, tmp_path, reduce_path):
     m = fx.golden(name)
     bases, off = fx.make_reads(m["synth"])
@@ -48,8 +60,7 @@ def test_files_identical_to_reference(name, tmp_path, reduce_path):
     ctx.reads_save(rp)
     ctx.graph_save(gp)
     assert fx.md5_file(rp) == m["reads_md5"]
-    got, want = open(gp, "rb").read(), fx.golden_graph3(name)
-    assert len(got) == len(want) and got == want
+    assert fx.graph3_matches(gp, name)
     st, ref = ctx.overlap_stats(), m["counters"]
     assert st.contained_extension == ref["contained_extension"]
     assert st.contained_size == ref["contained_size"]
@@ -356,6 +367,11 @@ def test_device_organizer_equals_host_organizer(pd, k, monkeypatch):
     (dp, dl, df), dn, dms = out["device"]; (hp, hl, hf), hn, hms = out["host"]
     assert dms > 0 and hms == 0, "the device organiser must be the one that ran by default"
     assert dn == hn and np.array_equal(dl, hl) and np.array_equal(df, hf) and np.array_equal(dp, hp)
+    # ... and against the pinned restatement of readLoader.cpp:179-260 (ids, lengths, frequencies, packed bytes)
+    o = ol.Oracle(k, 8); o.add_reads_ascii(bases, off); o.organize()
+    op, ol_, of = o.export_reads(); w = min(dp.shape[1], op.shape[1])
+    assert o.counter("N") == dn and np.array_equal(dl, ol_) and np.array_equal(df, of) and np.array_equal(dp[:, :w - 1], op[:, :w - 1])
+    o.close()
 
 
 def test_full_size_properties_c2():
@@ -559,6 +575,10 @@ def test_device_organizer_long_runs_of_equal_prefixes(monkeypatch):
     (dp, dl, df), dn = out["device"]; (hp, hl, hf), hn = out["host"]
     assert dn == hn and np.array_equal(dl, hl) and np.array_equal(df, hf) and np.array_equal(dp, hp)
     assert int(df.max()) >= 3001
+    o = ol.Oracle(21, 8); o.add_reads_ascii(bases, off); o.organize()
+    op, ol_, of = o.export_reads(); w = min(dp.shape[1], op.shape[1])
+    assert o.counter("N") == dn and np.array_equal(dl, ol_) and np.array_equal(df, of) and np.array_equal(dp[:, :w - 1], op[:, :w - 1])
+    o.close()
 
 
 def test_device_organizer_full_sort_path_equals_default(monkeypatch):
@@ -592,6 +612,12 @@ def test_long_bucket_reduce_ranked_device_path_equals_serial_replay(monkeypatch)
     assert res["default"][4] > 0 and res["default"][3] > 100000
     assert res["default"][1:] == res["host"][1:]
     assert res["default"][0] == res["host"][0]
+    # ... and both against the pinned restatement of the reference (not only against each other)
+    monkeypatch.delenv("SAGE2OV_HOST_REDUCE", raising=False)
+    ctx = s2.Context(40); ctx.reads_add_ascii(bases, off); ctx.reads_organize(); ctx.run_steps23()
+    o = run_oracle(dict(k=40), bases, off)
+    assert_equals_oracle(ctx, o)
+    ctx.close(); o.close()
 
 
 def test_long_bucket_reduce_with_oversized_lists_equals_serial_replay(monkeypatch):
@@ -612,6 +638,11 @@ def test_long_bucket_reduce_with_oversized_lists_equals_serial_replay(monkeypatc
     assert res["default"][4] > 500 and res["default"][3] > 100000
     assert res["default"][1:] == res["host"][1:]
     assert res["default"][0] == res["host"][0]
+    monkeypatch.delenv("SAGE2OV_HOST_REDUCE", raising=False)
+    ctx = s2.Context(40); ctx.reads_add_ascii(bases, off); ctx.reads_organize(); ctx.run_steps23()
+    o = run_oracle(dict(k=40), bases, off)
+    assert_equals_oracle(ctx, o)
+    ctx.close(); o.close()
 
 
 @pytest.mark.parametrize("pd,k", [
@@ -637,6 +668,11 @@ def test_long_bucket_reduce_more_shapes_equal_serial_replay(pd, k, monkeypatch):
     assert res["default"][4] > 0 and res["default"][3] > 1000
     assert res["default"][1:] == res["host"][1:]
     assert res["default"][0] == res["host"][0]
+    monkeypatch.setenv("SAGE2OV_DEVICE_REDUCE_MIN", "1")
+    ctx = s2.Context(k); ctx.reads_add_ascii(bases, off); ctx.reads_organize(); ctx.run_steps23()
+    o = run_oracle(dict(k=k), bases, off)
+    assert_equals_oracle(ctx, o)
+    ctx.close(); o.close()
 
 
 def test_long_bucket_reduce_in_many_slices(monkeypatch):

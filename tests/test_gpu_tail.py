@@ -1,0 +1,48 @@
+"""GPU: acceptance through the UNCHANGED reference tail.  Files WRITTEN BY THE GPU PATH IN THIS TEST -- `sage2ov -M 3`
+(P.reads + P.graph3) and `sage2ov -M 4` (P.graph4) -- are handed to the reference binary (oracle/_ref/SAGE2, built from /root/reference
+by oracle/Makefile; it travels to the GPU box as a built file), which continues with `-m 4 -M 7` resp. `-m 5 -M 7`; the result is compared
+with the reference's own one-shot run of all seven steps on the same FASTA (main.cpp:141-148 loader, :246 / :290 contig and scaffold
+writers).  Error-free fixtures: contigs and scaffolds, byte for byte.  Noisy fixtures: the graph files the tail writes (P.graph5, P.graph6)
+-- the reference does not reproduce its own contigs across ANY restart on noisy data."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+import fixtures as fx
+import sage2_amd as s2
+
+pytestmark = pytest.mark.gpu
+REF = os.path.join(fx.ROOT, "oracle", "_ref", "SAGE2")
+CLI = os.path.join(fx.ROOT, "sage2_amd", "sage2ov")
+
+
+def _same(a, b):
+    return os.path.exists(a) and os.path.exists(b) and open(a, "rb").read() == open(b, "rb").read()
+
+
+@pytest.mark.parametrize("name,start", [("g1_clean100_k21", 4), ("g2_clean150_k40", 4), ("g6_k70_150", 4), ("g8_noisy250_k45", 4),
+                                        ("g1_clean100_k21", 5), ("g2_clean150_k40", 5), ("g6_k70_150", 5), ("g8_noisy250_k45", 5)])
+def test_reference_tail_on_gpu_written_files(name, start, tmp_path):
+    if not os.path.exists(REF):
+        pytest.skip("oracle/_ref/SAGE2 not built (it is built in the build container and travels with the snapshot)")
+    m = fx.golden(name)
+    fa = str(tmp_path / "x.fa"); s2.synth_write_fasta(fx.synth_params(m["synth"]), fa)
+    env = dict(os.environ, OMP_NUM_THREADS="8", LC_ALL="C")
+    k = str(m["k"])
+    # the GPU path writes the hand-over files ...
+    ours = str(tmp_path / "ours")
+    subprocess.run([CLI, "-f", fa, "-k", k, "-o", ours, "-p", "t", "-M", str(start - 1)], check=True, stdout=subprocess.DEVNULL)
+    assert fx.md5_file(os.path.join(ours, "t.reads")) == m["reads_md5"]
+    assert os.path.exists(os.path.join(ours, "t.graph%d" % (start - 1)))
+    # ... the unchanged reference continues from them ...
+    subprocess.run([REF, "-f", fa, "-k", k, "-o", ours, "-p", "t2", "-i", "t", "-m", str(start), "-M", "7", "-s"], check=True, env=env, stdout=subprocess.DEVNULL, cwd=str(tmp_path))
+    # ... and must end where its own one-shot run ends
+    full = str(tmp_path / "full")
+    subprocess.run([REF, "-f", fa, "-k", k, "-o", full, "-p", "t", "-M", "7", "-s"], check=True, env=env, stdout=subprocess.DEVNULL, cwd=str(tmp_path))
+    assert _same(os.path.join(ours, "t.graph3"), os.path.join(full, "t.graph3")) or start == 5
+    suffixes = [".graph5", ".graph6"] + (["_contig.fasta", "_scaffold.fasta"] if "clean" in name else [])
+    for sfx in suffixes:
+        assert _same(os.path.join(ours, "t2" + sfx), os.path.join(full, "t" + sfx)), f"{name} from step {start}: {sfx} differs"
+    shutil.rmtree(ours, ignore_errors=True); shutil.rmtree(full, ignore_errors=True)

@@ -6,7 +6,7 @@ import fixtures as fx
 import oracle_lib as ol
 
 
-@pytest.mark.parametrize("name", fx.golden_names())
+@pytest.mark.parametrize("name", fx.golden_names_all())
 def test_oracle_matches_reference_files(name, tmp_path):
     m = fx.golden(name)
     bases, off = fx.make_reads(m["synth"])
@@ -18,7 +18,7 @@ def test_oracle_matches_reference_files(name, tmp_path):
     o.write_reads(reads_p)
     o.write_graph3(g3_p)
     assert fx.md5_file(reads_p) == m["reads_md5"]
-    assert open(g3_p, "rb").read() == fx.golden_graph3(name)
+    assert fx.graph3_matches(g3_p, name)
     c, ref = o.counters(), m["counters"]
     assert c["N"] == ref["unique_reads"] and c["good_reads"] == ref["good_reads"]
     assert c["contained"] == ref["contained_extension"] and c["contained_size"] == ref["contained_size"]
