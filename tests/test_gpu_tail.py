@@ -22,8 +22,11 @@ def _same(a, b):
     return os.path.exists(a) and os.path.exists(b) and open(a, "rb").read() == open(b, "rb").read()
 
 
-@pytest.mark.parametrize("name,start", [("g1_clean100_k21", 4), ("g2_clean150_k40", 4), ("g6_k70_150", 4), ("g8_noisy250_k45", 4),
-                                        ("g1_clean100_k21", 5), ("g2_clean150_k40", 5), ("g6_k70_150", 5), ("g8_noisy250_k45", 5)])
+# Not usable here: g3 / g5 / g8 -- the reference's OWN one-shot run dies in its steps 5-7 on them (SIGFPE in the flow / mate-pair code); g4 / g9 --
+# high-copy repeats: the min-cost flow has ties that CS2 breaks by arc order, which no restart of the reference reproduces (DESIGN.md
+# section 10).  Their hand-over files (P.graph3, P.graph4) are compared byte for byte in test_gpu_parity.py / test_gpu_step4.py.
+@pytest.mark.parametrize("name,start", [("g1_clean100_k21", 4), ("g2_clean150_k40", 4), ("g6_k70_150", 4),
+                                        ("g1_clean100_k21", 5), ("g2_clean150_k40", 5), ("g6_k70_150", 5)])
 def test_reference_tail_on_gpu_written_files(name, start, tmp_path):
     if not os.path.exists(REF):
         pytest.skip("oracle/_ref/SAGE2 not built (it is built in the build container and travels with the snapshot)")
