@@ -14,6 +14,11 @@
 #include <vector>
 #include <chrono>
 #include <memory>
+#include <atomic>
+#include <thread>
+#include <sched.h>
+#include <pthread.h>
+#include <sys/mman.h>
 #include "sage2ov.h"
 #include "sage2ov_internal.h"
 
@@ -35,7 +40,7 @@ typedef unsigned int u32;
 
 enum { WS_SLOTS, WS_CNT, WS_WHERE, WS_BIG, WS_CSR, WS_SLOW, WS_NEED, WS_DEG, WS_OFFS, WS_CURSOR, WS_KEYS, WS_KEEP, WS_POS, WS_OWNER, WS_FINAL,
        WS_PARTIAL, WS_IDS, WS_NEAR, WS_HITS, WS_MINH, WS_OCNT, WS_OOFF, WS_OCUR, WS_ORDER, WS_MI1, WS_MICNT, WS_MICUR, WS_KREC, WS_SLOTMH, WS_RA_DEG, WS_RA_OFF, WS_RA_CUR, WS_RA_ENT, WS_RA_RM, WS_ORG_POOL, WS_ORG_OFF, WS_ORG_LEN, WS_ORG_IMG, WS_ORG_K0, WS_ORG_K1, WS_ORG_V0, WS_ORG_V1, WS_ORG_HIST, WS_ORG_HSCAN, WS_ORG_FLAG, WS_ORG_UID, WS_ORG_HEAD, WS_RR_IN, WS_RR_DEGP, WS_RR_OFFP, WS_RR_ENTP, WS_RR_OUTP, WS_RR_WIDX, WS_RR_RANK, WS_RR_CUR, WS_RA_HEAVY, WS_RA_HSIZE, WS_RA_HSCR, WS_RR_LEN, WS_RR_COFF, WS_RR_OUTC,
-       WS_PT_K0, WS_PT_K1, WS_PT_P0, WS_PT_P1, WS_PT_M0, WS_PT_M1, WS_PT_CNT, WS_PT_BASE, WS_PT_OFF, WS_PT_GOFF, WS_COUNT };   // ids of the workspace arena (Device::ws)
+       WS_PT_K0, WS_PT_K1, WS_PT_P0, WS_PT_P1, WS_PT_M0, WS_PT_M1, WS_PT_CNT, WS_PT_BASE, WS_PT_OFF, WS_PT_GOFF, WS_RR_LOC, WS_RR_RANKL, WS_COUNT };   // ids of the workspace arena (Device::ws)
 struct Device {
     int ordinal = 0;
     hipStream_t stream = nullptr;
@@ -623,51 +628,175 @@ int dev_unresolved_hits(Device* d, std::vector<Hit>& hits, uint64_t* n_unresolve
 // read is explored (:853-871); an entry is `to | twin << 31`.  An own hit is in the read's list iff the target was still unexplored
 // when the read was explored, a twin iff its source had been explored before; candidates of the reciprocal pass (hasCand) are always
 // there but their far ends are never explorable.  Returns rank[id] (1-based exploration order; 0: not an unresolved read).
-static void explore_order(const std::vector<u32>& ids, const std::vector<const u32*>& lists, const std::vector<u32>& lenp, const std::vector<uint8_t>& hasCand,
-                          u64 N, std::vector<u32>& rank) {
-    const size_t n = ids.size();
-    // per read id: where its list is, how long, whether candidates of the reciprocal pass hang on it -- one 16-byte record, one cache line per visit
-    struct PL { const u32* p; u32 n; u32 cand; };
-    std::vector<PL> pl(N + 2, PL{nullptr, 0, 0});
-    for (size_t w = 0; w < n; w++) pl[ids[w]] = PL{lists[w], lenp[w], (u32)hasCand[w] | 2u};     // bit 1: an unresolved read (a start of the outer loop, :513)
-    // by read id: 0 = unexplored (status 0), else the 1-based exploration order, bit 31 = marked (status 2, :679) -- one table, one look-up
-    rank.assign(N + 2, 0);
-    constexpr u32 MARK = 0x80000000u, RK = 0x7FFFFFFFu;
-    u32 ctr = 0;
-    constexpr u32 IDM = 0x3FFFFFFFu;                                             // entry = to | kind << 30: 0 both sides see each other, 1 own hit only, 2 twin only
-    // an own-only hit is in the list iff its target was explored later (or not yet), a twin-only one iff its source was explored earlier
-    auto present = [&](u32 rw, u32 e) -> bool { const u32 k = e >> 30; if (k == 0) return true; const u32 rt = rank[e & IDM] & RK; return k == 1 ? (rt == 0 || rt > rw) : (rt != 0 && rt < rw); };
-    std::vector<u32> queue;
-    auto explore_neighbours = [&](u32 r) {                                       // every still unexplored neighbour this read sees, in list order (:531-541)
-        const u32* plist = pl[r].p;
-        for (u32 x = 0, en = pl[r].n; x < en; x++) {
-            if (x + 16 < en) __builtin_prefetch(&rank[plist[x + 16] & IDM]);       // at 10 M reads the table (40 MB) is out of the caches
-            const u32 e = plist[x]; if ((e >> 30) == 2) continue;
-            const u32 to = e & IDM; if (rank[to] == 0) { rank[to] = ++ctr; queue.push_back(to); }
+// Both inner loops look for RARE entries (a still unexplored target; an explored but unmarked neighbour) among ~100 per list, so they are
+// written as "find the next entry that satisfies the test": eight entries per step with AVX2 gathers of rank[] where the host has them
+// (the walk is instruction-bound: 2 ns per entry visit with a scalar loop, 1.9 G visits per 10 M reads).  After every event the search
+// restarts behind it with fresh values, so a batch never acts on state that an event of the same batch has changed.
+// Tables of the walk live on 2 MB pages where the kernel hands them out (transparent huge pages, madvise mode): the walk's accesses are
+// spread over ~2 GB (lists) + 170 MB (tables), far beyond what a TLB of 4 KB pages covers.
+struct HugeBuf {
+    void* p = nullptr; size_t bytes = 0; bool registered = false;
+    void* get(size_t n) {
+        bytes = (std::max<size_t>(n, 1) + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1);
+        p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (p == MAP_FAILED) { p = nullptr; return nullptr; }
+        madvise(p, bytes, MADV_HUGEPAGE);
+        return p;
+    }
+    ~HugeBuf() { if (p) { if (registered) hipHostUnregister(p); munmap(p, bytes); } }
+};
+constexpr u32 XO_MARK = 0x80000000u, XO_RK = 0x7FFFFFFFu, XO_IDM = 0x3FFFFFFFu;
+struct XoScalar {
+    static inline u32 next_unexplored(const u32* plist, u32 x, u32 n, const u32* rank) {      // kind != 2 and rank[to] == 0
+        for (; x < n; x++) { const u32 e = plist[x]; if ((e >> 30) != 2u && rank[e & XO_IDM] == 0) return x; }
+        return n;
+    }
+    static inline u32 next_unmarked(const u32* plist, u32 x, u32 n, const u32* rank) {        // rank[to] != 0 and not marked
+        for (; x < n; x++) { const u32 v = rank[plist[x] & XO_IDM]; if (v != 0 && !(v & XO_MARK)) return x; }
+        return n;
+    }
+};
+#if defined(__x86_64__)
+#include <immintrin.h>
+struct XoAvx2 {
+    __attribute__((target("avx2"))) static inline u32 next_unexplored(const u32* plist, u32 x, u32 n, const u32* rank) {
+        const __m256i idm = _mm256_set1_epi32((int)XO_IDM), two = _mm256_set1_epi32(2), zero = _mm256_setzero_si256();
+        for (; x + 8 <= n; x += 8) {
+            const __m256i e = _mm256_loadu_si256((const __m256i*)(plist + x));
+            const __m256i v = _mm256_i32gather_epi32((const int*)rank, _mm256_and_si256(e, idm), 4);
+            const __m256i hit = _mm256_andnot_si256(_mm256_cmpeq_epi32(_mm256_srli_epi32(e, 30), two), _mm256_cmpeq_epi32(v, zero));
+            const int m = _mm256_movemask_ps(_mm256_castsi256_ps(hit));
+            if (m) return x + (u32)__builtin_ctz((unsigned)m);
         }
-    };
-    for (u32 id0 = 1; id0 <= (u32)N; id0++) {                                    // ascending ids, as the serial loop starts its searches
-        if (!(pl[id0].cand & 2u) || rank[id0] != 0) continue;
-        queue.clear(); size_t start = 0; queue.push_back(id0);
-        while (start < queue.size()) {
-            const u32 r1 = queue[start++];
-            if (rank[r1] == 0) rank[r1] = ++ctr;
-            const u32 rw = rank[r1] & RK, b1 = 0, e1 = pl[r1].n; const u32* plist = pl[r1].p;
-            bool any = (pl[r1].cand & 1u) != 0;
-            for (u32 x = b1; !any && x < e1; x++) any = present(rw, plist[x]);
-            if (!any) continue;                                                  // an empty list (:527)
-            if (!(rank[r1] & MARK)) { explore_neighbours(r1); rank[r1] |= MARK; }
-            for (u32 x = b1; x < e1; x++) {                                      // (:543-561) neighbours that are explored but not yet marked
-                if (x + 16 < e1) __builtin_prefetch(&rank[plist[x + 16] & IDM]);
-                const u32 e = plist[x], r2 = e & IDM, v2 = rank[r2];
-                if (v2 == 0 || (v2 & MARK)) continue;                            // unexplored, or marked already
-                const u32 k = e >> 30, rt = v2 & RK;
-                if (k == 1 ? !(rt > rw) : (k == 2 ? !(rt < rw) : false)) continue;  // not in this read's list
-                explore_neighbours(r2); rank[r2] |= MARK;
+        return XoScalar::next_unexplored(plist, x, n, rank);
+    }
+    __attribute__((target("avx2"))) static inline u32 next_unmarked(const u32* plist, u32 x, u32 n, const u32* rank) {
+        const __m256i idm = _mm256_set1_epi32((int)XO_IDM), zero = _mm256_setzero_si256();
+        for (; x + 8 <= n; x += 8) {
+            const __m256i e = _mm256_loadu_si256((const __m256i*)(plist + x));
+            const __m256i v = _mm256_i32gather_epi32((const int*)rank, _mm256_and_si256(e, idm), 4);
+            // explored (v != 0) and not marked (sign bit clear): v > 0 as a signed number
+            const int m = _mm256_movemask_ps(_mm256_castsi256_ps(_mm256_cmpgt_epi32(v, zero)));
+            if (m) return x + (u32)__builtin_ctz((unsigned)m);
+        }
+        return XoScalar::next_unmarked(plist, x, n, rank);
+    }
+};
+#endif
+// Everything here is indexed by a read's POSITION IN THE LOCALITY ORDER (1-based; the order the probe kernel uses: reads bucketed by their
+// global minimiser), not by its id: ids are ranks in lexicographic order, i.e. random with respect to the genome, and the walk touches
+// rank[] once per list entry -- with positions the ~100 neighbours of a read sit in a handful of cache lines.  `startOrder` lists the
+// positions of the unresolved reads in ASCENDING ID order (the order in which the serial loop starts its searches, :513).
+template <class F>
+static void explore_order_impl(const std::vector<u32>& pos, const std::vector<const u32*>& lists, const std::vector<u32>& lenp, const std::vector<uint8_t>& hasCand,
+                               u64 N, const std::vector<u32>& startOrder, std::vector<u32>& rankv) {
+    const size_t n = pos.size();
+    // per read: where its list is, how long, whether candidates of the reciprocal pass hang on it -- one 16-byte record, one cache line per visit
+    struct PL { const u32* p; u32 n; u32 cand; };
+    HugeBuf plBuf, rankBuf;
+    PL* const pl = (PL*)plBuf.get((N + 2) * sizeof(PL)); u32* const rank = (u32*)rankBuf.get((N + 2) * sizeof(u32));      // (fresh anonymous pages: zero)
+    if (!pl || !rank) { rankv.clear(); return; }
+    for (size_t w = 0; w < n; w++) pl[pos[w]] = PL{lists[w], lenp[w], (u32)hasCand[w] | 2u};     // bit 1: an unresolved read (a start of the outer loop, :513)
+    // rank by position: 0 = unexplored (status 0), else the 1-based exploration order, bit 31 = marked (status 2, :679) -- one table, one look-up
+    u32 ctr = 0;
+    // entry = to | kind << 30: 0 both sides see each other, 1 own hit only, 2 twin only.
+    // an own-only hit is in the list iff its target was explored later (or not yet), a twin-only one iff its source was explored earlier
+    auto present = [&](u32 rw, u32 e) -> bool { const u32 k = e >> 30; if (k == 0) return true; const u32 rt = rank[e & XO_IDM] & XO_RK; return k == 1 ? (rt == 0 || rt > rw) : (rt != 0 && rt < rw); };
+    // The queue is one array for the whole walk (every read enters it once), its fill level and the pop position are published for the
+    // run-ahead helper thread below.
+    struct Queue { u32* d; size_t n = 0; std::atomic<size_t> pub{0};
+                   void push_back(u32 v) { d[n++] = v; pub.store(n, std::memory_order_release); } size_t size() const { return n; } u32 operator[](size_t i) const { return d[i]; } } queue;
+    HugeBuf qBuf; queue.d = (u32*)qBuf.get((N + 2) * sizeof(u32)); if (!queue.d) { rankv.clear(); return; }
+    std::atomic<size_t> popPos{0}; std::atomic<bool> walkDone{false};
+    // Run-ahead helper: the critical path of a pop is the first touch of the list of the neighbour it marks (explored long ago, its list
+    // long evicted) and of the rank[] lines around it -- a pointer chase along the genome, one DRAM latency per pop.  A second thread, on
+    // a neighbouring core of this thread's core complex (shared L3) where it can be placed, replays the second loop READ-ONLY for the reads a few pops ahead of the
+    // walk (racy reads of rank[]: only hints) and touches the lists it would scan, so that they are in the shared caches when the walk
+    // arrives.  It changes nothing the walk reads; SAGE2OV_WALK_HELPER=0 turns it off.
+    std::thread helper;
+    { const char* ev = getenv("SAGE2OV_WALK_HELPER"); const bool want = ev ? atoi(ev) != 0 : std::thread::hardware_concurrency() > 1;
+      if (want) {
+        int sib = -1; const int me = sched_getcpu();
+        if (me >= 0) { char path[128]; snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", me);
+            if (FILE* f = fopen(path, "r")) { int a = -1, b = -1; char sep = 0; if (fscanf(f, "%d%c%d", &a, &sep, &b) >= 3) sib = a == me ? b : a; fclose(f); }
+            // measured (EPYC 9575F, 10 M reads): helper on the next core of the same 8-core complex (shared L3) 1.9 s, on the SMT sibling 2.3 s
+            // (it shares the walk's issue slots), no helper 3.3 s -- so the neighbour core is tried first
+            if (!getenv("SAGE2OV_WALK_SMT_SIBLING")) { const int nb = (me & ~7) | ((me + 1) & 7); cpu_set_t al; CPU_ZERO(&al); if (sched_getaffinity(0, sizeof al, &al) == 0 && CPU_ISSET(nb, &al)) sib = nb; } }
+        cpu_set_t allowed; CPU_ZERO(&allowed); if (sib >= 0 && (sched_getaffinity(0, sizeof allowed, &allowed) != 0 || !CPU_ISSET(sib, &allowed))) sib = -1;
+        cpu_set_t saved; CPU_ZERO(&saved); bool pinnedMain = false;
+        if (sib >= 0 && pthread_getaffinity_np(pthread_self(), sizeof saved, &saved) == 0) { cpu_set_t one; CPU_ZERO(&one); CPU_SET(me, &one); pinnedMain = pthread_setaffinity_np(pthread_self(), sizeof one, &one) == 0; }
+        static const int AHEAD = getenv("SAGE2OV_WALK_AHEAD") ? atoi(getenv("SAGE2OV_WALK_AHEAD")) : 4, WINDOW = 24;
+        helper = std::thread([&, sib]() {
+            if (sib >= 0) { cpu_set_t one; CPU_ZERO(&one); CPU_SET(sib, &one); pthread_setaffinity_np(pthread_self(), sizeof one, &one); }
+            size_t done = 0; u32 sink = 0;
+            while (!walkDone.load(std::memory_order_acquire)) {
+                const size_t s0 = popPos.load(std::memory_order_relaxed), e0 = queue.pub.load(std::memory_order_acquire);
+                size_t a = std::max(done, s0 + (size_t)AHEAD), b = std::min(e0, s0 + (size_t)AHEAD + WINDOW);
+                if (a >= b) { __builtin_ia32_pause(); continue; }
+                for (size_t i = a; i < b; i++) {
+                    const PL nx = pl[queue.d[i]]; const u32* q = nx.p; if (!q) continue;
+                    for (u32 x = 0; x < nx.n; x++) {
+                        const u32 to = q[x] & XO_IDM; const u32 v = __atomic_load_n(&rank[to], __ATOMIC_RELAXED);
+                        if (v != 0 && !(v & XO_MARK)) { const PL t = pl[to]; if (t.p) for (u32 o = 0; o < t.n; o += 16) sink += __atomic_load_n(t.p + o, __ATOMIC_RELAXED); }
+                    }
+                }
+                done = b;
             }
+            if (sink == 0x9E3779B9u) fprintf(stderr, " ");                        // (keeps the loads alive)
+        });
+        (void)pinnedMain; (void)saved;
+      } }
+    struct HelperJoin { std::thread& t; std::atomic<bool>& d; ~HelperJoin() { d.store(true, std::memory_order_release); if (t.joinable()) t.join(); } } helperJoin{helper, walkDone};
+    u64 tcA = 0, tcB = 0, tcC = 0, tcD = 0;
+    u64 stPops = 0, stMarks = 0, stScanA = 0, stScanB = 0, stAnyFalse = 0, stEvB = 0, stStarts = 0; const bool stats = getenv("SAGE2OV_TIMING") != nullptr;
+    auto explore_neighbours = [&](u32 r) {                                       // every still unexplored neighbour this read sees, in list order (:531-541)
+        const u32* plist = pl[r].p; const u32 en = pl[r].n; stMarks++; stScanA += en;
+        const u64 t0_ = stats ? __builtin_ia32_rdtsc() : 0;
+        for (u32 x = F::next_unexplored(plist, 0, en, rank); x < en; x = F::next_unexplored(plist, x + 1, en, rank)) {
+            const u32 to = plist[x] & XO_IDM; rank[to] = ++ctr; queue.push_back(to);
+            static const int PFE = getenv("SAGE2OV_WALK_PFE") ? atoi(getenv("SAGE2OV_WALK_PFE")) : 1;
+            if (PFE) { const PL& t = pl[to]; if (t.p) { __builtin_prefetch(t.p); __builtin_prefetch(t.p + 16); __builtin_prefetch(t.p + 32); __builtin_prefetch(t.p + 48); } }   // it is marked (its list scanned) within a few pops
+        }
+        if (stats) tcA += __builtin_ia32_rdtsc() - t0_;
+    };
+    for (u32 p0 : startOrder) {                                                  // ascending ids, as the serial loop starts its searches
+        if (!(pl[p0].cand & 2u) || rank[p0] != 0) continue;
+        size_t start = queue.size(); queue.push_back(p0); stStarts++;              // (the queue is never cleared: a search starts where the last one ended)
+        while (start < queue.size()) {
+            const u32 r1 = queue[start++]; stPops++; popPos.store(start, std::memory_order_relaxed);
+            if (start + 8 < queue.size()) { const PL& nx = pl[queue[start + 8]]; if (nx.p) for (u32 o = 0; o < nx.n; o += 16) __builtin_prefetch(nx.p + o); }   // the popped read's own list, 8 pops ahead
+            const u64 t1_ = stats ? __builtin_ia32_rdtsc() : 0;
+            if (rank[r1] == 0) rank[r1] = ++ctr;
+            const u32 rw = rank[r1] & XO_RK, e1 = pl[r1].n; const u32* plist = pl[r1].p;
+            bool any = (pl[r1].cand & 1u) != 0;
+            for (u32 x = 0; !any && x < e1; x++) any = present(rw, plist[x]);
+            if (stats) tcB += __builtin_ia32_rdtsc() - t1_;
+            if (!any) { stAnyFalse++; continue; }                                // an empty list (:527)
+            if (!(rank[r1] & XO_MARK)) { explore_neighbours(r1); rank[r1] |= XO_MARK; }
+            stScanB += e1;
+            const u64 t2_ = stats ? __builtin_ia32_rdtsc() : 0; const u64 a0_ = tcA;
+            // (:543-561) neighbours that are explored but not yet marked
+            for (u32 x = F::next_unmarked(plist, 0, e1, rank); x < e1; x = F::next_unmarked(plist, x + 1, e1, rank)) {
+                const u32 e = plist[x], r2 = e & XO_IDM, k = e >> 30, rt = rank[r2] & XO_RK;
+                if (k == 1 ? !(rt > rw) : (k == 2 ? !(rt < rw) : false)) continue;  // not in this read's list
+                explore_neighbours(r2); rank[r2] |= XO_MARK; stEvB++;
+            }
+            if (stats) tcC += (__builtin_ia32_rdtsc() - t2_) - (tcA - a0_);
         }
     }
-    for (u32 id : ids) rank[id] &= RK;
+    if (stats) fprintf(stderr, "[walk] Mcycles: explore_neighbours %llu, pop head + any %llu, second loop (without the explores) %llu\n", (unsigned long long)(tcA >> 20), (unsigned long long)(tcB >> 20), (unsigned long long)(tcC >> 20));
+    (void)tcD;
+    if (stats) fprintf(stderr, "[walk] starts %llu pops %llu (empty %llu) marks %llu (by a neighbour %llu) entries scanned: explore %llu, second loop %llu\n", (unsigned long long)stStarts, (unsigned long long)stPops,
+                       (unsigned long long)stAnyFalse, (unsigned long long)stMarks, (unsigned long long)stEvB, (unsigned long long)stScanA, (unsigned long long)stScanB);
+    for (u32 q : pos) rank[q] &= XO_RK;
+    rankv.assign(rank, rank + N + 2);
+}
+static void explore_order(const std::vector<u32>& pos, const std::vector<const u32*>& lists, const std::vector<u32>& lenp, const std::vector<uint8_t>& hasCand,
+                          u64 N, const std::vector<u32>& startOrder, std::vector<u32>& rank) {
+#if defined(__x86_64__)
+    if (__builtin_cpu_supports("avx2") && !getenv("SAGE2OV_WALK_SCALAR")) { explore_order_impl<XoAvx2>(pos, lists, lenp, hasCand, N, startOrder, rank); return; }
+#endif
+    explore_order_impl<XoScalar>(pos, lists, lenp, hasCand, N, startOrder, rank);
 }
 
 int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved, uint64_t* n_hits, uint64_t* inserted, uint64_t* removed, int* done, std::string& err) {
@@ -698,8 +827,20 @@ int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved
     // groups), the sequential kernel for the few reads it hands over (> 128 candidates, ambiguous tags) and for the 16-word layout
     Hit* dh = nullptr; u64 nh = 0, nslots = 0;
     WS(hitcount, u32, WS_RA_CUR, N + 2);
+    u32* locDev = nullptr;                                                       // ranked form: read id -> 1-based position in the locality order
     {
         u32* order = nullptr; { int rc = build_locality_order(d, 1, N + 1, &order, err); if (rc) return rc; }
+        if (ranked) {
+            WS(lc, u32, WS_RR_LOC, N + 2); locDev = lc; HIPCHK(hipMemsetAsync(lc, 0, (N + 2) * sizeof(u32), d->stream));
+            hipLaunchKernelGGL(k_rr_loc, dim3(grid_for(N, 256)), dim3(256), 0, d->stream, order, (u64)N, lc);
+            // the unresolved reads listed in LOCALITY order (a stable compaction of `order`): their potential lists are then laid out in that
+            // order too, so the lists the host's walk visits one after the other sit next to each other in memory (cache lines, TLB)
+            WS(flg, u32, WS_RR_IN, N + 2); WS(fpos, u32, WS_RR_WIDX, N + 2);
+            hipLaunchKernelGGL(k_rr_unres_flag, dim3(grid_for(N, 256)), dim3(256), 0, d->stream, order, (u64)N, d->status, flg);
+            u64 cnt2 = 0; { int rc = scan_u32(d, flg, N, fpos, &cnt2, err); if (rc) return rc; }
+            if (cnt2 != nun) { err = "unresolved read count changed"; return SAGE2OV_ERR_INTERNAL; }
+            hipLaunchKernelGGL(k_rr_unres_pick, dim3(grid_for(N, 256)), dim3(256), 0, d->stream, order, (u64)N, flg, fpos, ids);
+        }
         WS(slow, u32, WS_SLOW, N + 1);
         const unsigned blocks = (unsigned)std::min<u64>((N + FAST_CHUNK - 1) / FAST_CHUNK, 256ull * 16);
         u64 cap = std::max<u64>(1 << 16, nun * 80) + (u64)blocks * SAGE2OV_FAST_WPB * HITS_CHUNK; bool ok = false;
@@ -742,20 +883,23 @@ int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved
         // potential lists (own hits + twins of incoming hits), sorted and merged on the device, slice by slice (a slice stays below 2^30
         // entries); exploration order on the host; ranks back
         WS(incount, u32, WS_RR_IN, N + 2); WS(widx, u32, WS_RR_WIDX, N + 2); WS(degp, u32, WS_RR_DEGP, nun + 2); WS(pcur, u32, WS_RR_CUR, N + 2);
-        HIPCHK(hipMemsetAsync(incount, 0, (N + 2) * sizeof(u32), d->stream)); HIPCHK(hipMemsetAsync(pcur, 0, (N + 2) * sizeof(u32), d->stream));
+        HIPCHK(hipMemsetAsync(incount, 0, (N + 2) * sizeof(u32), d->stream)); HIPCHK(hipMemsetAsync(pcur, 0, (N + 2) * sizeof(u32), d->stream)); HIPCHK(hipMemsetAsync(widx, 0, (N + 2) * sizeof(u32), d->stream));
         hipLaunchKernelGGL(k_rr_widx, dim3(grid_for(nun, 256)), dim3(256), 0, d->stream, ids, (u64)nun, widx);
         if (nslots) hipLaunchKernelGGL(k_rr_incount, dim3(grid_for(nslots, 256)), dim3(256), 0, d->stream, dh, (u64)nslots, incount);
         hipLaunchKernelGGL(k_rr_degp, dim3(grid_for(nun, 256)), dim3(256), 0, d->stream, ids, (u64)nun, hitcount, incount, degp);
-        std::vector<u32> hIds(nun), hLen(nun, 0), hDeg(N + 2), hDegp(nun); std::vector<uint8_t> hasCand(nun, 0); std::vector<const u32*> listPtr(nun, nullptr);
+        std::vector<u32> hIds(nun), hLen(nun, 0), hDeg(N + 2), hDegp(nun), hLoc(N + 2); std::vector<uint8_t> hasCand(nun, 0); std::vector<const u32*> listPtr(nun, nullptr);
+        HIPCHK(hipMemcpyAsync(hLoc.data(), locDev, (N + 2) * sizeof(u32), hipMemcpyDeviceToHost, d->stream));
         HIPCHK(hipMemcpyAsync(hDegp.data(), degp, nun * sizeof(u32), hipMemcpyDeviceToHost, d->stream));
         HIPCHK(hipMemcpyAsync(hIds.data(), ids, nun * sizeof(u32), hipMemcpyDeviceToHost, d->stream));
         HIPCHK(hipMemcpyAsync(hDeg.data(), deg, (N + 2) * sizeof(u32), hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));   // (deg so far: candidate entries only)
         for (u64 w = 0; w < nun; w++) hasCand[w] = hDeg[hIds[w]] != 0;
         if (timing) { u64 c512 = 0, c1k = 0, c4k = 0; u32 mx = 0; for (u32 v : hDegp) { c512 += v > 512; c1k += v > 1024; c4k += v > 4096; mx = std::max(mx, v); }
             fprintf(stderr, "[reduce/device] potential lists: %llu reads, > 512: %llu, > 1024: %llu, > 4096: %llu, longest %u\n", (unsigned long long)nun, (unsigned long long)c512, (unsigned long long)c1k, (unsigned long long)c4k, mx); }
-        struct Staging { std::vector<u32*> pinned; std::vector<std::vector<u32>> pageable; ~Staging() { for (u32* p : pinned) hipHostFree(p); }
-                         u32* get(size_t n) { u32* p = nullptr; if (hipHostMalloc((void**)&p, std::max<size_t>(n, 16) * sizeof(u32), hipHostMallocDefault) == hipSuccess) { pinned.push_back(p); return p; }
-                                              (void)hipGetLastError(); pageable.emplace_back(std::max<size_t>(n, 16)); return pageable.back().data(); } } staging;   // gigabytes at 10 M reads: DMA into pinned memory when there is some
+        struct Staging { std::vector<std::unique_ptr<HugeBuf>> bufs;
+                         u32* get(size_t n) { bufs.emplace_back(new HugeBuf()); HugeBuf& b = *bufs.back(); u32* p = (u32*)b.get((std::max<size_t>(n, 16) + 16) * sizeof(u32)); if (!p) return nullptr;
+                                              memset(p, 0, b.bytes);                                  // (touch: the pages exist before they are pinned)
+                                              if (hipHostRegister(p, b.bytes, hipHostRegisterDefault) == hipSuccess) b.registered = true; else (void)hipGetLastError();
+                                              return p; } } staging;   // gigabytes at 10 M reads: 2 MB pages for the host's walk, registered so that the download is a DMA
         std::vector<std::vector<u32>> heavyLists;                                 // lists beyond the device sort (reads that thousands of others see): sorted and merged on the host
         u64 sliceEntries = 1ull << 30; if (const char* ev = getenv("SAGE2OV_TEST_RANK_SLICE")) sliceEntries = std::max<u64>(1024, strtoull(ev, nullptr, 10));
         WS(lenp, u32, WS_RR_LEN, nun + 2);
@@ -771,8 +915,8 @@ int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved
             hipLaunchKernelGGL(k_rr_sortp, dim3((unsigned)std::min<u64>((nw + 3) / 4, 256ull * 16)), dim3(256), 0, d->stream, (u64)nw, offp, degp + w0, entp, outp, lenp + w0, d->d_counters + 8 + 3);
             u64 totc = 0; { int rc = scan_u32(d, lenp + w0, nw, coff, &totc, err); if (rc) return rc; }
             WS(outc, u32, WS_RR_OUTC, totc + 64);
-            hipLaunchKernelGGL(k_rr_compact, dim3((unsigned)std::min<u64>((nw + 3) / 4, 256ull * 16)), dim3(256), 0, d->stream, (u64)nw, offp, lenp + w0, coff, outp, outc);
-            u32* hbuf = staging.get(totc);
+            hipLaunchKernelGGL(k_rr_compact, dim3((unsigned)std::min<u64>((nw + 3) / 4, 256ull * 16)), dim3(256), 0, d->stream, (u64)nw, offp, lenp + w0, coff, outp, locDev, outc);
+            u32* hbuf = staging.get(totc); if (!hbuf) { err = "host staging buffer allocation failed"; return SAGE2OV_ERR_NOMEM; }
             HIPCHK(hipMemcpyAsync(hLen.data() + w0, lenp + w0, nw * sizeof(u32), hipMemcpyDeviceToHost, d->stream));
             if (totc) HIPCHK(hipMemcpyAsync(hbuf, outc, totc * sizeof(u32), hipMemcpyDeviceToHost, d->stream));
             HIPCHK(hipStreamSynchronize(d->stream));
@@ -789,7 +933,7 @@ int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved
                         const bool twin = kx & 1ull;
                         if (!twin && x > 0 && (seg[x - 1] & 1ull) && (seg[x - 1] >> 1) == (kx >> 1)) continue;      // the own hit behind its twin: merged
                         const bool sym = twin && x + 1 < n && seg[x + 1] != 0 && !(seg[x + 1] & 1ull) && (seg[x + 1] >> 1) == (kx >> 1);
-                        hl.push_back((u32)(kx >> 11) | ((sym ? 0u : (twin ? 2u : 1u)) << 30));
+                        hl.push_back(hLoc[(u32)(kx >> 11) & 0x3FFFFFFFu] | ((sym ? 0u : (twin ? 2u : 1u)) << 30));
                     }
                     hLen[w] = (u32)hl.size();
                 }
@@ -799,10 +943,18 @@ int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved
         }
         { size_t hx = 0; for (u64 w = 0; w < nun; w++) if (hDegp[w] > (u32)RR_CAP) listPtr[w] = heavyLists[hx++].data(); }      // (after the last push_back: the vectors no longer move)
         lap("potential lists (build + sort + download)");
-        std::vector<u32> rankById; explore_order(hIds, listPtr, hLen, hasCand, N, rankById);
+        std::vector<u32> rankByPos, posOf(nun), startOrder;
+        for (u64 w = 0; w < nun; w++) posOf[w] = hLoc[hIds[w]];
+        { std::vector<uint8_t> isUn(N + 2, 0); for (u64 w = 0; w < nun; w++) isUn[hIds[w]] = 1; startOrder.reserve(nun); for (u64 id = 1; id <= N; id++) if (isUn[id]) startOrder.push_back(hLoc[id]); }
+        lap("walk set-up (host)");
+        explore_order(posOf, listPtr, hLen, hasCand, N, startOrder, rankByPos);
+        if (rankByPos.size() != N + 2) { err = "exploration walk: table allocation failed"; return SAGE2OV_ERR_NOMEM; }
         lap("exploration order (host)");
         { WS(rk, u32, WS_RR_RANK, N + 2); rankDev = rk; }
-        HIPCHK(hipMemcpy(rankDev, rankById.data(), (N + 2) * sizeof(u32), hipMemcpyHostToDevice));
+        { WS(rl, u32, WS_RR_RANKL, N + 2);
+          HIPCHK(hipMemcpyAsync(rl, rankByPos.data(), (N + 2) * sizeof(u32), hipMemcpyHostToDevice, d->stream));
+          hipLaunchKernelGGL(k_rr_rank_by_id, dim3(grid_for(N + 2, 256)), dim3(256), 0, d->stream, rl, locDev, (u64)(N + 2), rankDev);
+          HIPCHK(hipStreamSynchronize(d->stream)); }
         if (nslots) hipLaunchKernelGGL(k_rr_degree_h, dim3(grid_for(nslots, 256)), dim3(256), 0, d->stream, dh, (u64)nslots, rankDev, deg, d->d_counters + 8);
     } else hipLaunchKernelGGL(k_ra_degree_h, dim3(grid_for(N + 1, 256)), dim3(256), 0, d->stream, hitcount, (u64)N, deg);
     u64 tot = 0; { int rc = scan_u32(d, deg, N + 2, offs, &tot, err); if (rc) return rc; }
