@@ -713,7 +713,7 @@ static void explore_order_impl(const std::vector<u32>& pos, const std::vector<co
     // a neighbouring core of this thread's core complex (shared L3) where it can be placed, replays the second loop READ-ONLY for the reads a few pops ahead of the
     // walk (racy reads of rank[]: only hints) and touches the lists it would scan, so that they are in the shared caches when the walk
     // arrives.  It changes nothing the walk reads; SAGE2OV_WALK_HELPER=0 turns it off.
-    std::thread helper;
+    std::thread helper; cpu_set_t savedMask; CPU_ZERO(&savedMask); bool pinnedMain = false;
     { const char* ev = getenv("SAGE2OV_WALK_HELPER"); const bool want = ev ? atoi(ev) != 0 : std::thread::hardware_concurrency() > 1;
       if (want) {
         int sib = -1; const int me = sched_getcpu();
@@ -723,8 +723,7 @@ static void explore_order_impl(const std::vector<u32>& pos, const std::vector<co
             // (it shares the walk's issue slots), no helper 3.3 s -- so the neighbour core is tried first
             if (!getenv("SAGE2OV_WALK_SMT_SIBLING")) { const int nb = (me & ~7) | ((me + 1) & 7); cpu_set_t al; CPU_ZERO(&al); if (sched_getaffinity(0, sizeof al, &al) == 0 && CPU_ISSET(nb, &al)) sib = nb; } }
         cpu_set_t allowed; CPU_ZERO(&allowed); if (sib >= 0 && (sched_getaffinity(0, sizeof allowed, &allowed) != 0 || !CPU_ISSET(sib, &allowed))) sib = -1;
-        cpu_set_t saved; CPU_ZERO(&saved); bool pinnedMain = false;
-        if (sib >= 0 && pthread_getaffinity_np(pthread_self(), sizeof saved, &saved) == 0) { cpu_set_t one; CPU_ZERO(&one); CPU_SET(me, &one); pinnedMain = pthread_setaffinity_np(pthread_self(), sizeof one, &one) == 0; }
+        if (sib >= 0 && pthread_getaffinity_np(pthread_self(), sizeof savedMask, &savedMask) == 0) { cpu_set_t one; CPU_ZERO(&one); CPU_SET(me, &one); pinnedMain = pthread_setaffinity_np(pthread_self(), sizeof one, &one) == 0; }   // (restored when the walk ends)
         static const int AHEAD = getenv("SAGE2OV_WALK_AHEAD") ? atoi(getenv("SAGE2OV_WALK_AHEAD")) : 4, WINDOW = 24;
         helper = std::thread([&, sib]() {
             if (sib >= 0) { cpu_set_t one; CPU_ZERO(&one); CPU_SET(sib, &one); pthread_setaffinity_np(pthread_self(), sizeof one, &one); }
@@ -744,9 +743,9 @@ static void explore_order_impl(const std::vector<u32>& pos, const std::vector<co
             }
             if (sink == 0x9E3779B9u) fprintf(stderr, " ");                        // (keeps the loads alive)
         });
-        (void)pinnedMain; (void)saved;
       } }
-    struct HelperJoin { std::thread& t; std::atomic<bool>& d; ~HelperJoin() { d.store(true, std::memory_order_release); if (t.joinable()) t.join(); } } helperJoin{helper, walkDone};
+    struct HelperJoin { std::thread& t; std::atomic<bool>& d; cpu_set_t& m; bool& pinned;
+                        ~HelperJoin() { d.store(true, std::memory_order_release); if (t.joinable()) t.join(); if (pinned) pthread_setaffinity_np(pthread_self(), sizeof m, &m); } } helperJoin{helper, walkDone, savedMask, pinnedMain};
     u64 tcA = 0, tcB = 0, tcC = 0, tcD = 0;
     u64 stPops = 0, stMarks = 0, stScanA = 0, stScanB = 0, stAnyFalse = 0, stEvB = 0, stStarts = 0; const bool stats = getenv("SAGE2OV_TIMING") != nullptr;
     auto explore_neighbours = [&](u32 r) {                                       // every still unexplored neighbour this read sees, in list order (:531-541)
