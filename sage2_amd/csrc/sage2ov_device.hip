@@ -40,14 +40,17 @@ typedef unsigned int u32;
 
 enum { WS_SLOTS, WS_CNT, WS_WHERE, WS_BIG, WS_CSR, WS_SLOW, WS_NEED, WS_DEG, WS_OFFS, WS_CURSOR, WS_KEYS, WS_KEEP, WS_POS, WS_OWNER, WS_FINAL,
        WS_PARTIAL, WS_IDS, WS_NEAR, WS_HITS, WS_MINH, WS_OCNT, WS_OOFF, WS_OCUR, WS_ORDER, WS_MI1, WS_MICNT, WS_MICUR, WS_KREC, WS_SLOTMH, WS_RA_DEG, WS_RA_OFF, WS_RA_CUR, WS_RA_ENT, WS_RA_RM, WS_ORG_POOL, WS_ORG_OFF, WS_ORG_LEN, WS_ORG_IMG, WS_ORG_K0, WS_ORG_K1, WS_ORG_V0, WS_ORG_V1, WS_ORG_HIST, WS_ORG_HSCAN, WS_ORG_FLAG, WS_ORG_UID, WS_ORG_HEAD, WS_RR_IN, WS_RR_DEGP, WS_RR_OFFP, WS_RR_ENTP, WS_RR_OUTP, WS_RR_WIDX, WS_RR_RANK, WS_RR_CUR, WS_RA_HEAVY, WS_RA_HSIZE, WS_RA_HSCR, WS_RR_LEN, WS_RR_COFF, WS_RR_OUTC,
-       WS_PT_K0, WS_PT_K1, WS_PT_P0, WS_PT_P1, WS_PT_M0, WS_PT_M1, WS_PT_CNT, WS_PT_BASE, WS_PT_OFF, WS_PT_GOFF, WS_RR_LOC, WS_RR_RANKL, WS_COUNT };   // ids of the workspace arena (Device::ws)
+       WS_PT_K0, WS_PT_K1, WS_PT_P0, WS_PT_P1, WS_PT_M0, WS_PT_M1, WS_PT_CNT, WS_PT_BASE, WS_PT_OFF, WS_PT_GOFF, WS_RR_LOC, WS_RR_RANKL, WS_LOC_READS, WS_LOC_IDOF, WS_LOC_POSOF, WS_LOC_STATUS, WS_COUNT };   // ids of the workspace arena (Device::ws)
 struct Device {
     int ordinal = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev[8] = {};
     // reads
     u64 N = 0; int S = 0, maxL = 0, k = 0, h = 0;
-    u64* reads = nullptr;        // (N+1)*S words
+    u64* reads = nullptr;        // (N+1)*S words, slot i = read id i
+    // the same reads in LOCALITY order (slot p = the read at position p of the order by global minimiser): what the index entries point at and
+    // what the probe kernels gather from -- a read's overlap partners are neighbours in the genome, hence (mostly) neighbours here
+    u64* readsLoc = nullptr; u32* idOf = nullptr; u32* posOf = nullptr; uint8_t* statusP = nullptr;
     // index
     u64 T = 0; u64* slots = nullptr; u32* csr = nullptr; u64 n_csr = 0; u64 seed = 0x5A6E2D0Full;
     u64 n_keys = 0, n_long = 0;
@@ -239,6 +242,35 @@ int dev_organize_reads(Device* d, const uint64_t* pool, uint64_t pool_words, con
     return 0;
 }
 
+static int build_locality_order(Device* d, u64 lo, u64 hi, u32** order_out, std::string& err);
+// The locality-ordered copy of the read store + the two translation tables (see Device::readsLoc).  Part of the index build (timed with it).
+__global__ void k_loc_store(const u64* __restrict__ reads, const u32* __restrict__ order, u64 N, int S, u64* out, u32* idOf, u32* posOf) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < (u64)S) out[t] = 0ull;                                                      // slot 0: zeros (the target of gated-off gathers)
+    if (t == 0) { idOf[0] = 0; posOf[0] = 0; idOf[N + 1] = 0; posOf[N + 1] = 0; }
+    if (t >= N * S) return;
+    const u64 p = t / S; const int c = (int)(t % S); const u32 id = order ? order[p] : (u32)(p + 1);
+    out[(p + 1) * S + c] = reads[(u64)id * S + c];
+    if (c == 0) { idOf[p + 1] = id; posOf[id] = (u32)(p + 1); }
+}
+__global__ void k_status_by_pos(const u32* __restrict__ idOf, const uint8_t* __restrict__ status, u64 N, uint8_t* statusP) {
+    const u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x; if (p > N) return; statusP[p] = p ? status[idOf[p]] : (uint8_t)0xFF;
+}
+__global__ void k_ids_to_pos(const u32* __restrict__ ids, u64 n, const u32* __restrict__ posOf, u32* out) { const u64 x = (u64)blockIdx.x * blockDim.x + threadIdx.x; if (x < n) out[x] = posOf[ids[x]]; }
+static int build_locality_store(Device* d, std::string& err) {
+    const u64 N = d->N;
+    WS(rl, u64, WS_LOC_READS, (N + 1) * d->S); WS(io, u32, WS_LOC_IDOF, N + 2); WS(po, u32, WS_LOC_POSOF, N + 2); WS(sp, uint8_t, WS_LOC_STATUS, N + 2);
+    d->readsLoc = rl; d->idOf = io; d->posOf = po; d->statusP = sp;
+    u32* order = nullptr;
+    if (N && !getenv("SAGE2OV_NO_LOCALITY")) { int rc = build_locality_order(d, 1, N + 1, &order, err); if (rc) return rc; }
+    hipLaunchKernelGGL(k_loc_store, dim3(grid_for(std::max<u64>(N * d->S, d->S), 256)), dim3(256), 0, d->stream, d->reads, order, (u64)N, d->S, rl, io, po);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+static int refresh_status_by_pos(Device* d, std::string& err) {
+    hipLaunchKernelGGL(k_status_by_pos, dim3(grid_for(d->N + 1, 256)), dim3(256), 0, d->stream, d->idOf, d->status, (u64)d->N, d->statusP);
+    HIPCHK(hipGetLastError()); return 0;
+}
 // exclusive scan without the read-back of the total (no host synchronisation)
 static int scan_u32_async(Device* d, const u32* in, u64 n, u32* out, std::string& err);
 
@@ -281,6 +313,7 @@ static void pt_first_digit(u64 nWin, int shiftW, int* shift0, u32* mask0, int* d
 int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t* csr_out, uint64_t* nlong_out, uint32_t* rebuilds, std::string& err) {
     HIPCHK(hipSetDevice(d->ordinal));
     const u64 N = d->N; if (!d->reads) { err = "reads not resident"; return SAGE2OV_ERR_ARG; }
+    { int rc = build_locality_store(d, err); if (rc) return rc; }
     d->T = std::max<u64>(IX_W, (8 * N + IX_W - 1) / IX_W * IX_W);            // load <= 0.5, as hashTable.cpp:83 sizes it; whole windows
     if (d->T >= (1ull << 32)) { err = "table too large for 32-bit slot indices"; return SAGE2OV_ERR_LIMIT; }
     const u64 nW = d->T / IX_W; const u32 n = (u32)(4 * N);
@@ -314,7 +347,7 @@ int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t
         HIPCHK(hipMemsetAsync(d->d_counters + 8, 0, 9 * sizeof(u64), d->stream));
         // ---- tuples of the 4N entries, sorted by the window of their home slot
         int shift0, doHist; u32 mask0; pt_first_digit(nW, IX_WPLOG, &shift0, &mask0, &doHist);
-        if (n) hipLaunchKernelGGL(k_ix_tuples, dim3(ntiles), dim3(PT_THREADS), 0, d->stream, d->reads, (u32)N, d->S, d->h, d->seed, (u32)(d->T >> 1), wantMI ? 1 : 0, shift0, mask0, doHist,
+        if (n) hipLaunchKernelGGL(k_ix_tuples, dim3(ntiles), dim3(PT_THREADS), 0, d->stream, d->readsLoc, (u32)N, d->S, d->h, d->seed, (u32)(d->T >> 1), wantMI ? 1 : 0, shift0, mask0, doHist,
                                   B.K[0], B.P[0], B.M[0], cnt, ntiles);
         lap("tuples");
         int cur = 0;
@@ -322,7 +355,7 @@ int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t
         lap("partition by table window");
         // ---- the windows of the uniform table, built in LDS; group tuples into the free buffer set
         IxWinArgs A; A.K = B.K[cur]; A.P = B.P[cur]; A.M = wantMI ? B.M[cur] : nullptr; A.winOff = winOff; A.nW = (u32)nW; A.slots = d->slots; A.csr = d->csr;
-        A.counters = d->d_counters + 8; A.big = big; A.big_cap = big_cap; A.gK = wantMI ? B.K[cur ^ 1] : nullptr; A.gP = wantMI ? B.P[cur ^ 1] : nullptr; A.wh = (u64*)B.P[cur ^ 1] ;
+        A.counters = d->d_counters + 8; A.big = big; A.big_cap = big_cap; A.idOf = d->idOf; A.gK = wantMI ? B.K[cur ^ 1] : nullptr; A.gP = wantMI ? B.P[cur ^ 1] : nullptr; A.wh = (u64*)B.P[cur ^ 1] ;
         // (the scratch words of heavy windows and the group tuples share no buffer: tuples go to P[other] via gP, scratch needs its own)
         { WS(whs, u64, WS_WHERE, nAlloc); A.wh = whs; }
         hipLaunchKernelGGL(k_ix_window, dim3((unsigned)std::min<u64>(nW, 256ull * 6)), dim3(256), 0, d->stream, A);      // persistent: two rounds of 3 workgroups per CU, each with ONE pair of statistics atomics
@@ -333,7 +366,7 @@ int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t
         if (c[8]) { err = "index build: a key occurs in more than 16 M reads, or a table window overflowed"; return SAGE2OV_ERR_LIMIT; }
         if (c[2] > big_cap) { err = "too many long buckets"; return SAGE2OV_ERR_LIMIT; }
         if (c[2]) {
-            hipLaunchKernelGGL(k_index_purity, dim3(grid_for(c[2] * 64, 256)), dim3(256), 0, d->stream, d->reads, d->S, d->h, big, c[2], d->csr, d->d_counters + 8);
+            hipLaunchKernelGGL(k_index_purity, dim3(grid_for(c[2] * 64, 256)), dim3(256), 0, d->stream, d->readsLoc, d->S, d->h, big, c[2], d->csr, d->d_counters + 8);
             HIPCHK(hipMemcpyAsync(c, d->d_counters + 8, 5 * sizeof(u64), hipMemcpyDeviceToHost, d->stream));
             HIPCHK(hipStreamSynchronize(d->stream));
         }
@@ -357,7 +390,7 @@ int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t
                 d->n_groups = mc[1];
                 if (getenv("SAGE2OV_VERIFY_MI")) {
                     u64* vo = nullptr; HIPCHK(hipMalloc(&vo, 2 * sizeof(u64))); HIPCHK(hipMemsetAsync(vo, 0, 2 * sizeof(u64), d->stream));
-                    hipLaunchKernelGGL(k_mi_verify, dim3(grid_for(4 * N, 256)), dim3(256), 0, d->stream, d->reads, N, d->S, d->h, d->seed, d->slots, d->T, mi1, TL, krec, vo);
+                    hipLaunchKernelGGL(k_mi_verify, dim3(grid_for(4 * N, 256)), dim3(256), 0, d->stream, d->readsLoc, N, d->S, d->h, d->seed, d->slots, d->T, mi1, TL, krec, vo);
                     u64 hv2[2]; HIPCHK(hipMemcpyAsync(hv2, vo, sizeof hv2, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream)); hipFree(vo);
                     fprintf(stderr, "[verify-mi] %llu of %llu entries do not find their bucket in their key's group\n", (unsigned long long)hv2[0], (unsigned long long)hv2[1]);
                 }
@@ -380,7 +413,7 @@ int dev_lookup(Device* d, uint64_t hi, uint64_t lo, uint64_t* entries, uint32_t 
     if (!d->slots) { err = "index not built"; return SAGE2OV_ERR_ARG; }
     u64* out = nullptr; const u32 c2 = std::min<u32>(cap, 128);
     HIPCHK(hipMalloc(&out, (129) * sizeof(u64)));
-    hipLaunchKernelGGL(k_lookup, dim3(1), dim3(1), 0, d->stream, d->slots, d->T, d->csr, d->seed, d->h, (u64)hi, (u64)lo, out, c2);
+    hipLaunchKernelGGL(k_lookup, dim3(1), dim3(1), 0, d->stream, d->slots, d->T, d->csr, d->idOf, d->seed, d->h, (u64)hi, (u64)lo, out, c2);
     u64 host[129];
     HIPCHK(hipMemcpyAsync(host, out, sizeof host, hipMemcpyDeviceToHost, d->stream));
     HIPCHK(hipStreamSynchronize(d->stream));
@@ -412,7 +445,10 @@ static int build_locality_order(Device* d, u64 lo, u64 hi, u32** order_out, std:
     const u64 n = hi - lo;
     // reads sorted by the top bits of their global minimiser's hash (two radix passes, kernels_partition.inc; the order inside a bucket
     // of equal top bits is free): 18 bits or one bucket per ~16 reads, whichever is coarser
-    int lg = 10; while (lg < 18 && (1ull << lg) < n / 16) lg++;
+    // 27 bits of the hash (three passes): reads with one minimiser end up next to each other -- measured at BASELINE configs[2]: probe kernel
+    // 149 -> 142 ms from the finer processing order alone, 120 ms with the read store in that order too
+    int lg = 27;
+    if (const char* ev = getenv("SAGE2OV_ORDER_BITS")) lg = std::max(1, std::min(32, atoi(ev)));
     const u32 ntiles = (u32)((n + PT_TILE - 1) / PT_TILE);
     PtBufs B; B.P[0] = B.P[1] = nullptr;
     { WS(a, u32, WS_MINH, n + 4); B.K[0] = a; } { WS(a, u32, WS_OCUR, n + 4); B.K[1] = a; }
@@ -425,7 +461,7 @@ static int build_locality_order(Device* d, u64 lo, u64 hi, u32** order_out, std:
 }
 static ProbeArgs base_args(Device* d) {
     ProbeArgs A; memset(&A, 0, sizeof A);
-    A.reads = d->reads; A.N = d->N; A.S = d->S; A.k = d->k; A.h = d->h; A.slots = d->slots; A.T = d->T; A.csr = d->csr; A.seed = d->seed;
+    A.reads = d->readsLoc; A.idOf = d->idOf; A.statusP = d->statusP; A.N = d->N; A.S = d->S; A.k = d->k; A.h = d->h; A.slots = d->slots; A.T = d->T; A.csr = d->csr; A.seed = d->seed;
     A.right = d->right; A.left = d->left; A.conn = d->conn; A.cflag = d->cflag; A.status = d->status; A.counters = d->d_counters;
     A.mi1 = d->mi1; A.TL = d->TL; A.krec = d->krec; A.uniL = d->uniL;
     return A;
@@ -462,7 +498,7 @@ int dev_probe(Device* d, uint64_t lo, uint64_t hi, std::string& err) {
     if (nreads && !seq_only) {
         WS(slow, u32, WS_SLOW, nreads);
         A.slow = slow; A.slow_cap = nreads;
-        if (!getenv("SAGE2OV_NO_LOCALITY")) { u32* order = nullptr; int rc = build_locality_order(d, lo, hi, &order, err); if (rc) return rc; A.ids = order; A.n_ids = nreads; }
+        // (positions [lo, hi) of the locality order: consecutive items are neighbours in the genome AND in the read store)
         const unsigned blocks = (unsigned)std::min<u64>((nreads + FAST_CHUNK - 1) / FAST_CHUNK, 256ull * 16);
 #ifdef SAGE2OV_STAMPS
         static u64* d_stamps = nullptr;
@@ -471,7 +507,7 @@ int dev_probe(Device* d, uint64_t lo, uint64_t hi, std::string& err) {
 #endif
         HIPCHK(hipEventRecord(d->ev[2], d->stream));
         const bool launched = launch_fast_any<0>(d, A, blocks);               // false: 16-word layout, sequential kernel only (for now)
-        if (!launched) { A.ids = nullptr; A.n_ids = 0; int rc = launch_probe<0>(d, A, err); if (rc) return rc; }
+        if (!launched) { int rc = launch_probe<0>(d, A, err); if (rc) return rc; }
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(d->ev[3], d->stream));
         u64 nslow = 0;
@@ -501,13 +537,14 @@ int dev_probe(Device* d, uint64_t lo, uint64_t hi, std::string& err) {
 }
 
 struct Record { u64 right, left; u32 conn, cflag; };
-__global__ void k_pack_records(u64 lo, u64 hi, const u64* right, const u64* left, const u32* conn, const u32* cflag, Record* out) {
-    u64 i = lo + (u64)blockIdx.x * blockDim.x + threadIdx.x; if (i >= hi) return;
-    Record r; r.right = right[i]; r.left = left[i]; r.conn = conn[i]; r.cflag = cflag[i]; out[i - lo] = r;
+// (a rank probes a range of POSITIONS of the locality order; the per-read arrays are indexed by id)
+__global__ void k_pack_records(u64 lo, u64 hi, const u32* __restrict__ idOf, const u64* right, const u64* left, const u32* conn, const u32* cflag, Record* out) {
+    u64 p = lo + (u64)blockIdx.x * blockDim.x + threadIdx.x; if (p >= hi) return;
+    const u32 i = idOf[p]; Record r; r.right = right[i]; r.left = left[i]; r.conn = conn[i]; r.cflag = cflag[i]; out[p - lo] = r;
 }
-__global__ void k_unpack_records(u64 first, u64 n, const Record* in, u64* right, u64* left, u32* conn, u32* cflag, bool own) {
+__global__ void k_unpack_records(u64 first, u64 n, const u32* __restrict__ idOf, const Record* in, u64* right, u64* left, u32* conn, u32* cflag, bool own) {
     u64 x = (u64)blockIdx.x * blockDim.x + threadIdx.x; if (x >= n) return;
-    Record r = in[x]; u64 i = first + x; right[i] = r.right; left[i] = r.left; conn[i] = r.conn;
+    Record r = in[x]; const u32 i = idOf[first + x]; right[i] = r.right; left[i] = r.left; conn[i] = r.conn;
     (void)own; cflag[i] |= r.cflag;       // containment marks (economyGraph.cpp:735) are OR-ed, never overwritten: the local probe may have marked read i too
 }
 // containment flags travel as two byte planes (bit0 plane, bit1 plane) so that a MAX all-reduce is a bitwise OR
@@ -544,13 +581,13 @@ int dev_set_cands(Device* d, const void* src, uint64_t n, std::string& err) {   
 }
 int dev_export_records(Device* d, void* dst, uint64_t lo, uint64_t hi, std::string& err) {
     HIPCHK(hipSetDevice(d->ordinal));
-    if (hi > lo) hipLaunchKernelGGL(k_pack_records, dim3(grid_for(hi - lo, 256)), dim3(256), 0, d->stream, (u64)lo, (u64)hi, d->right, d->left, d->conn, d->cflag, (Record*)dst);
+    if (hi > lo) hipLaunchKernelGGL(k_pack_records, dim3(grid_for(hi - lo, 256)), dim3(256), 0, d->stream, (u64)lo, (u64)hi, d->idOf, d->right, d->left, d->conn, d->cflag, (Record*)dst);
     HIPCHK(hipStreamSynchronize(d->stream));
     return 0;
 }
 int dev_import_records(Device* d, const void* src, uint64_t first, uint64_t n, std::string& err) {
     HIPCHK(hipSetDevice(d->ordinal));
-    if (n) hipLaunchKernelGGL(k_unpack_records, dim3(grid_for(n, 256)), dim3(256), 0, d->stream, (u64)first, (u64)n, (const Record*)src, d->right, d->left, d->conn, d->cflag, false);
+    if (n) hipLaunchKernelGGL(k_unpack_records, dim3(grid_for(n, 256)), dim3(256), 0, d->stream, (u64)first, (u64)n, d->idOf, (const Record*)src, d->right, d->left, d->conn, d->cflag, false);
     HIPCHK(hipStreamSynchronize(d->stream));
     return 0;
 }
@@ -603,7 +640,9 @@ int dev_unresolved_hits(Device* d, std::vector<Hit>& hits, uint64_t* n_unresolve
         WS(dh, Hit, WS_HITS, cap);
         HIPCHK(hipMemsetAsync(d->d_counters + 4, 0, sizeof(u64), d->stream));
         ProbeArgs A = base_args(d); A.hits = dh; A.hits_cap = cap;
-        { WS(idbuf, u32, WS_IDS, nun); A.ids = idbuf; A.n_ids = nun; }    // the list dev_unresolved_ids left on the device: only these reads are probed
+        { WS(idbuf, u32, WS_IDS, nun); WS(pbuf, u32, WS_SLOW, nun + 1);      // the list dev_unresolved_ids left on the device, as positions: only these reads are probed
+          hipLaunchKernelGGL(k_ids_to_pos, dim3(grid_for(nun, 256)), dim3(256), 0, d->stream, idbuf, (u64)nun, d->posOf, pbuf); A.ids = pbuf; A.n_ids = nun; }
+        rc = refresh_status_by_pos(d, err); if (rc) return rc;
         rc = launch_probe<1>(d, A, err); if (rc) return rc;
         u64 nh = 0;
         HIPCHK(hipMemcpyAsync(&nh, d->d_counters + 4, sizeof nh, hipMemcpyDeviceToHost, d->stream));
@@ -828,10 +867,10 @@ int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved
     WS(hitcount, u32, WS_RA_CUR, N + 2);
     u32* locDev = nullptr;                                                       // ranked form: read id -> 1-based position in the locality order
     {
-        u32* order = nullptr; { int rc = build_locality_order(d, 1, N + 1, &order, err); if (rc) return rc; }
+        { int rc = refresh_status_by_pos(d, err); if (rc) return rc; }
+        const u32* order = d->idOf + 1;                                            // ids in locality order (positions 1..N)
         if (ranked) {
-            WS(lc, u32, WS_RR_LOC, N + 2); locDev = lc; HIPCHK(hipMemsetAsync(lc, 0, (N + 2) * sizeof(u32), d->stream));
-            hipLaunchKernelGGL(k_rr_loc, dim3(grid_for(N, 256)), dim3(256), 0, d->stream, order, (u64)N, lc);
+            locDev = d->posOf;
             // the unresolved reads listed in LOCALITY order (a stable compaction of `order`): their potential lists are then laid out in that
             // order too, so the lists the host's walk visits one after the other sit next to each other in memory (cache lines, TLB)
             WS(flg, u32, WS_RR_IN, N + 2); WS(fpos, u32, WS_RR_WIDX, N + 2);
@@ -849,7 +888,7 @@ int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved
             HIPCHK(hipMemsetAsync(d->d_counters + 4, 0, 3 * sizeof(u64), d->stream));
             HIPCHK(hipMemsetAsync(hitcount, 0, (N + 2) * sizeof(u32), d->stream));
             ProbeArgs A = base_args(d); A.lo = 1; A.hi = N + 1; A.hits = dh; A.hits_cap = cap; A.hitcount = hitcount;
-            A.ids = order; A.n_ids = N; A.slow = slow; A.slow_cap = N + 1;
+            A.slow = slow; A.slow_cap = N + 1;                                       // (all positions; the kernel skips what is not status 0)
             u64 c3[3] = {0, 0, 0};
             if (launch_fast_any<1>(d, A, blocks)) {
                 HIPCHK(hipGetLastError());
@@ -860,7 +899,7 @@ int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved
                     int rc = launch_probe<1>(d, B, err); if (rc) return rc;
                 }
             } else {
-                A.ids = nullptr; A.n_ids = 0; A.slow = nullptr;
+                A.slow = nullptr;
                 int rc = launch_probe<1>(d, A, err); if (rc) return rc;
             }
             u64 used = 0;
@@ -1066,7 +1105,7 @@ int dev_debug_all_hits(Device* d, std::vector<Hit>& hits, std::string& err) {
     HIPCHK(hipMalloc(&dh, cap * sizeof(Hit)));
     HIPCHK(hipMemsetAsync(d->d_counters + 4, 0, sizeof(u64), d->stream));
     ProbeArgs A = base_args(d); A.lo = 1; A.hi = N + 1; A.hits = dh; A.hits_cap = cap;
-    int rc = launch_probe<1>(d, A, err);
+    int rc = refresh_status_by_pos(d, err); if (!rc) rc = launch_probe<1>(d, A, err);
     u64 nh = 0;
     if (!rc) { HIPCHK(hipMemcpyAsync(&nh, d->d_counters + 4, sizeof nh, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream)); }
     if (!rc && nh > cap) { err = "debug hit buffer too small"; rc = SAGE2OV_ERR_LIMIT; }
