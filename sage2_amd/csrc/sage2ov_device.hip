@@ -347,7 +347,7 @@ int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t
         HIPCHK(hipMemsetAsync(d->d_counters + 8, 0, 9 * sizeof(u64), d->stream));
         // ---- tuples of the 4N entries, sorted by the window of their home slot
         int shift0, doHist; u32 mask0; pt_first_digit(nW, IX_WPLOG, &shift0, &mask0, &doHist);
-        if (n) hipLaunchKernelGGL(k_ix_tuples, dim3(ntiles), dim3(PT_THREADS), 0, d->stream, d->readsLoc, (u32)N, d->S, d->h, d->seed, (u32)(d->T >> 1), wantMI ? 1 : 0, shift0, mask0, doHist,
+        if (n) hipLaunchKernelGGL(k_ix_tuples, dim3(ntiles), dim3(PT_THREADS), 0, d->stream, d->reads, d->posOf, (u32)N, d->S, d->h, d->seed, (u32)(d->T >> 1), wantMI ? 1 : 0, shift0, mask0, doHist,
                                   B.K[0], B.P[0], B.M[0], cnt, ntiles);
         lap("tuples");
         int cur = 0;
@@ -642,7 +642,6 @@ int dev_unresolved_hits(Device* d, std::vector<Hit>& hits, uint64_t* n_unresolve
         ProbeArgs A = base_args(d); A.hits = dh; A.hits_cap = cap;
         { WS(idbuf, u32, WS_IDS, nun); WS(pbuf, u32, WS_SLOW, nun + 1);      // the list dev_unresolved_ids left on the device, as positions: only these reads are probed
           hipLaunchKernelGGL(k_ids_to_pos, dim3(grid_for(nun, 256)), dim3(256), 0, d->stream, idbuf, (u64)nun, d->posOf, pbuf); A.ids = pbuf; A.n_ids = nun; }
-        rc = refresh_status_by_pos(d, err); if (rc) return rc;
         rc = launch_probe<1>(d, A, err); if (rc) return rc;
         u64 nh = 0;
         HIPCHK(hipMemcpyAsync(&nh, d->d_counters + 4, sizeof nh, hipMemcpyDeviceToHost, d->stream));

@@ -41,8 +41,9 @@ if pk:
     if f:
         tj = os.path.join(prof, "probe_traffic.json")
         cur = json.load(open(tj)) if os.path.exists(tj) else {}
-        wl = bench["config"]["workload"].split(" x ")
-        key = f"{wl[0]}x150_k40"
+        import re
+        m = re.match(r"(\d+) x (\d+) bp .*?k=(\d+).*?seed (\d+)", bench["config"]["workload"])
+        key = f"{m.group(1)}x{m.group(2)}_k{m.group(3)}_seed{m.group(4)}"
         cur[key] = {"bytes_per_launch": rd_bytes + w * 1024.0, "read_bytes": rd_bytes, "write_bytes": w * 1024.0, "fetch_KiB_as_reported": f, "write_KiB": w,
                     "read_requests_128B": r128, "kernel": k, "source": f"profiles/{tag}_pmc_summary.txt",
                     "note": "reads = TCC_EA0_RDREQ_128B x 128 B (all read requests are 128-byte lines; FETCH_SIZE tallies them at 64 B, cf. MI355X_MICROARCH.md HBM section)"}

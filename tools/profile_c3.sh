@@ -4,7 +4,7 @@
 set -e
 export TMPDIR=/tmp
 R=$PWD; O=$R/gpurun_out/c3; mkdir -p $O
-ARGS="--reads 50000000 --genome 150000000 --no-cpu-baseline --no-noisy-variant --no-step4 --steps 3 --warmup 1"
+ARGS="--no-cpu-baseline --no-noisy-variant --no-c2 --no-step4 --steps 3 --warmup 1"     # bench.py defaults to configs[2] (50 M reads, seed 3)
 cd $R
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o c3 -- python3 bench.py $ARGS > $O/bench_stats.log 2>&1
 echo stats done
