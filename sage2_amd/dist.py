@@ -63,22 +63,29 @@ def allreduce_flags(planes: torch.Tensor, group=None):
     return planes
 
 
-def allgather_edge_buckets(bucket: torch.Tensor, n_edges: int, group=None):
-    """bucket: uint8 tensor with this rank's n_edges*16 bytes (may be longer).  Returns the concatenation of
-    all ranks' buckets in rank order and the total edge count."""
+def allgather_edge_buckets(bucket: torch.Tensor, n_edges: int, group=None, cap_edges: int = None):
+    """bucket: uint8 tensor with this rank's n_edges*16 bytes (may be longer).  Returns the concatenation of all ranks' buckets in
+    rank order and the total edge count.  ONE collective: every rank sends a fixed-size buffer = a 16-byte header (its edge count) +
+    `cap_edges` edge slots, so no count exchange (and no device-to-host round trip) precedes the payload.  cap_edges must bound every
+    rank's bucket; the caller knows such a bound (a rank emits at most 2 edges per read it owns in the reciprocal pass).  Without a
+    bound the counts are exchanged first (two collectives)."""
     world = dist.get_world_size(group)
-    cnt = torch.tensor([n_edges], dtype=torch.int64, device=bucket.device)
-    cnts = torch.empty(world, dtype=torch.int64, device=bucket.device)
-    _all_gather(cnts, cnt, group)
-    cnts = cnts.cpu().tolist()
-    pad = max(max(cnts), 1) * EDGE_BYTES
-    send = torch.zeros(pad, dtype=torch.uint8, device=bucket.device)
-    send[: n_edges * EDGE_BYTES] = bucket[: n_edges * EDGE_BYTES]
-    recv = torch.empty(world * pad, dtype=torch.uint8, device=bucket.device)
+    if cap_edges is None:
+        cnt = torch.tensor([n_edges], dtype=torch.int64, device=bucket.device)
+        cnts = torch.empty(world, dtype=torch.int64, device=bucket.device)
+        _all_gather(cnts, cnt, group)
+        cap_edges = max(int(cnts.max().item()), 1)
+    assert n_edges <= cap_edges, "edge bucket larger than the agreed capacity"
+    slot = (1 + cap_edges) * EDGE_BYTES
+    send = torch.zeros(slot, dtype=torch.uint8, device=bucket.device)
+    send[:8] = torch.tensor([n_edges], dtype=torch.int64).view(torch.uint8).to(bucket.device)
+    send[EDGE_BYTES: EDGE_BYTES + n_edges * EDGE_BYTES] = bucket[: n_edges * EDGE_BYTES]
+    recv = torch.empty(world * slot, dtype=torch.uint8, device=bucket.device)
     _all_gather(recv, send, group)
     _sync(recv)
-    parts = [recv[r * pad: r * pad + cnts[r] * EDGE_BYTES] for r in range(world)]
-    return torch.cat(parts) if parts else recv[:0], sum(cnts)
+    heads = recv.view(world, slot)[:, :8].contiguous().cpu().view(torch.int64).reshape(world).tolist()      # (after the payload has arrived: no extra collective)
+    parts = [recv[r * slot + EDGE_BYTES: r * slot + EDGE_BYTES + heads[r] * EDGE_BYTES] for r in range(world)]
+    return torch.cat(parts) if parts else recv[:0], sum(heads)
 
 
 def run_steps23_sharded(ctx, device, group=None):
@@ -109,6 +116,8 @@ def run_steps23_sharded(ctx, device, group=None):
     bucket = torch.zeros(max(ne, 1) * EDGE_BYTES, dtype=torch.uint8, device=device)
     _sync(bucket)
     ctx.shard_edges_export(bucket.data_ptr(), max(ne, 1))
+    # (counts first, then buckets padded to the largest: the only a-priori bound -- two edges per read of the range -- would double the bytes
+    # of the one-collective form, which costs more over xGMI than the 8-byte count exchange it saves)
     allb, total = allgather_edge_buckets(bucket, ne, group)
     allb = allb.contiguous()
     _sync(allb)
