@@ -110,6 +110,10 @@ int sage2ov_index_stats_get(const sage2ov_ctx* ctx, sage2ov_index_stats* out);
  * (key[0]=v0 leading bases, key[1]=v1 last 32 bases, utils.cpp:171-187).  Entries are id*4+type in
  * bucket order; *count = 0 for "not found" (absent or long).  Test/diagnostic entry point. */
 int sage2ov_index_lookup(sage2ov_ctx* ctx, const uint64_t key[2], uint64_t* entries, uint32_t cap, uint32_t* count);
+/* saveHashTableInFile (hashTable.cpp:256-273, :12-20) -> P.hashTable: the slot-by-slot text dump of the REFERENCE's double-hashed table (what
+ * `SAGE2 -m 3` loads).  Our index has another shape, so the reference's serial insertion (hashTable.cpp:94-109, :133-187: table size, start
+ * slot, probe step, 101-entry cap, long-bucket flag) is replayed on the host for this file alone.  Needs organised reads only (no GPU). */
+int sage2ov_hashtable_save(sage2ov_ctx* ctx, const char* path);
 
 /* ---- STEP 3: EconomyGraph + OverlapGraph::convertGraph ---- */
 typedef struct sage2ov_overlap_stats {

@@ -56,18 +56,39 @@ def counters(log):
             "contained_extension": r"Total contained by extension:\s*(\d+)", "contained_size": r"Total contained by size:\s*(\d+)",
             "left_to_explore": r"Total left to explore:\s*(\d+)", "edges_inserted": r"Total edges inserted:\s*(\d+)",
             "transitive_removed": r"Transitive edge removed:\s*(\d+)", "long_buckets": r"hash elements over threshold:\s*(\d+)",
-            "hash_string_length": r"Hash string length:\s*(\d+)"}
+            "hash_string_length": r"Hash string length:\s*(\d+)", "hash_table_size": r"Hash table size:\s*(\d+)"}
     out = {}
     for k, p in pats.items():
         m = re.search(p, txt)
         if m: out[k] = int([g for g in m.groups() if g][0])
     return out
 
+# P.hashTable only (`SAGE2 -M 2 -s`): a read set big enough for the safe-prime part of the reference's table-size list (8N > 1 000 003)
+HASHTABLE_ONLY = {
+    "h1_c2_1m_k40": (40, 8, dict(seed=2, genome_len=3_000_000, n_reads=1_000_000, read_len=150)),
+}
+
+def make_hashtable_only(lib, gold):
+    for name, (k, threads, pd) in HASHTABLE_ONLY.items():
+        tmp = tempfile.mkdtemp(prefix="sage2gold_")
+        try:
+            fa = os.path.join(tmp, "x.fa"); p = SynthParams(**pd)
+            assert lib.sage2ov_synth_write_fasta(ctypes.byref(p), fa.encode()) == 0
+            env = dict(os.environ, OMP_NUM_THREADS=str(threads), LC_ALL="C")
+            subprocess.run([REF, "-f", fa, "-k", str(k), "-o", os.path.join(tmp, "out"), "-p", "t", "-M", "2", "-s"], check=True, env=env, stdout=subprocess.DEVNULL)
+            ht, reads, log = (os.path.join(tmp, "out", "t." + e) for e in ("hashTable", "reads", "log"))
+            meta = dict(name=name, k=k, ref_threads=threads, synth=pd, reads_md5=md5(reads), hashtable_md5=md5(ht), hashtable_size=os.path.getsize(ht), counters=counters(log))
+            json.dump(meta, open(os.path.join(gold, name + ".hashtable.json"), "w"), indent=1, sort_keys=True)
+            print(name, meta["counters"], "hashTable", meta["hashtable_size"])
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+
 def main():
     lib = ctypes.CDLL(sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "sage2_amd", "libsage2ov.so"))
     lib.sage2ov_synth_write_fasta.argtypes = [ctypes.POINTER(SynthParams), ctypes.c_char_p]
     gold = os.path.join(ROOT, "tests", "golden"); os.makedirs(gold, exist_ok=True)
     only = set(sys.argv[2:])
+    if not only or "hashtable" in only: make_hashtable_only(lib, gold)
     for name, (k, threads, pd) in FIXTURES.items():
         if only and name not in only: continue
         tmp = tempfile.mkdtemp(prefix="sage2gold_")
@@ -87,6 +108,8 @@ def main():
             meta = dict(name=name, k=k, ref_threads=threads, synth=pd, fasta_md5=md5(fa),
                         reads_md5=md5(reads), reads_size=os.path.getsize(reads),
                         graph3_md5=md5(g3), graph3_size=os.path.getsize(g3), counters=counters(log))
+            ht = os.path.join(tmp, "out", "t.hashTable")                     # (-s: the reference also dumped its table, hashTable.cpp:256)
+            meta["hashtable_md5"], meta["hashtable_size"] = md5(ht), os.path.getsize(ht)
             if os.path.getsize(g3) <= 4 << 20:
                 with open(g3, "rb") as fi, gzip.GzipFile(os.path.join(gold, name + ".graph3.gz"), "wb", mtime=0) as fo:
                     shutil.copyfileobj(fi, fo)

@@ -212,6 +212,9 @@ class Context:
         self._chk(lib().sage2ov_index_stats_get(self._h, C.byref(s)))
         return s
 
+    def hashtable_save(self, path):
+        self._chk(lib().sage2ov_hashtable_save(self._h, path.encode()))
+
     def index_lookup(self, v0, v1, cap=128):
         key = (C.c_uint64 * 2)(v0, v1)
         ent = (C.c_uint64 * cap)()

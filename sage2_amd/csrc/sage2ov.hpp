@@ -49,6 +49,7 @@ class HashTable {
 public:
     explicit HashTable(ReadLoader* loader1) : loaderObj(loader1) {}
     void hashPrefixesAndSuffix() { loaderObj->context().check(sage2ov_index_build(loaderObj->context().get())); }
+    void saveHashTableInFile(const std::string& path) { loaderObj->context().check(sage2ov_hashtable_save(loaderObj->context().get(), path.c_str())); }   // hashTable.cpp:256
     sage2ov_index_stats stats() const { sage2ov_index_stats s{}; loaderObj->context().check(sage2ov_index_stats_get(loaderObj->context().get(), &s)); return s; }
     ReadLoader* loaderObj;
 };

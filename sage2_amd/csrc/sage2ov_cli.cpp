@@ -107,7 +107,9 @@ int main(int argc, char* argv[]) {
                       << "\n\t Number of hash elements over threshold: " << is.long_buckets << "\n\tStep 2 in " << now() - t0 << " sec.\n";
             if (lastStep == 2) {
                 if (minStep == 1 && !saveAll) { double tw = now(); loaderObj.saveReadsInFile(outputDir + prefixName + ".reads"); logStream << "\t" << prefixName << ".reads written in " << now() - tw << " sec.\n"; }
-                logStream << "\t(P.hashTable is not written: SAGE2 -m 4 does not need it and sage2ov -m 3 rebuilds the index)\n";
+            }
+            if (lastStep == 2 || saveAll) {                                                   // main.cpp:80-81: P.hashTable with -s or when the run ends here
+                double tw = now(); hashObj.saveHashTableInFile(outputDir + prefixName + ".hashTable"); logStream << "\t" << prefixName << ".hashTable written in " << now() - tw << " sec.\n";
             }
             if (lastStep >= 3) {                                                              // main.cpp:92-132
                 EconomyGraph economyObj(&hashObj);

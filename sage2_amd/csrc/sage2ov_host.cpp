@@ -736,6 +736,97 @@ int sage2ov_index_lookup(sage2ov_ctx* c, const uint64_t key[2], uint64_t* entrie
     return dev_lookup(c->dev, key[0], key[1], entries, cap, count, c->err);
 }
 
+// P.hashTable (hashTable.cpp:256-273, :12-20): the text dump of the REFERENCE's own table -- one line per slot of its double-hashed table, in
+// slot order -- which SAGE2 writes with -s or -M 2 and reads back with -m 3.  Our index has another shape, so the file
+// is produced by replaying the reference's serial insertion (hashTable.cpp:94-109, :133-187) on the host: same table size (:243-254), same
+// start slot (:233), same probe step (:140), same cap of 101 entries per bucket (:178), same flag for buckets of >= 100 entries (:111-123).
+// Only the file needs this; look-ups never do (the placement is invisible in P.graph3).
+namespace {
+// The reference picks its table size from a literal list of 450 primes (hashTable.cpp:246).  The list follows a rule, which is what is
+// implemented here instead of the list: k * 100000 < p prime, smallest, for k = 1..10; then the smallest SAFE prime (p and (p-1)/2 prime)
+// above m * 65536 for m = mant * 2^e, mant = 17..31, e = 0, 1, 2, ... starting at m = 27.  (Checked against the reference's numbers when the
+// golden fixtures were made: oracle/make_golden.py records the table size the reference printed; tests/test_hashtable_file.py.)
+inline uint64_t mulmod64(uint64_t a, uint64_t b, uint64_t m) { return (uint64_t)((unsigned __int128)a * b % m); }
+inline uint64_t powmod64(uint64_t a, uint64_t e, uint64_t m) { uint64_t r = 1; a %= m; while (e) { if (e & 1) r = mulmod64(r, a, m); a = mulmod64(a, a, m); e >>= 1; } return r; }
+bool is_prime64(uint64_t n) {
+    if (n < 2) return false;
+    for (uint64_t p : {2ull, 3ull, 5ull, 7ull, 11ull, 13ull, 17ull, 19ull, 23ull, 29ull, 31ull, 37ull}) { if (n % p == 0) return n == p; }
+    uint64_t d = n - 1; int r = 0; while ((d & 1) == 0) { d >>= 1; r++; }
+    for (uint64_t a : {2ull, 3ull, 5ull, 7ull, 11ull, 13ull, 17ull, 19ull, 23ull, 29ull, 31ull, 37ull}) {          // deterministic for 64-bit n
+        uint64_t x = powmod64(a, d, n); if (x == 1 || x == n - 1) continue;
+        bool comp = true; for (int i = 1; i < r; i++) { x = mulmod64(x, x, n); if (x == n - 1) { comp = false; break; } }
+        if (comp) return false;
+    }
+    return true;
+}
+// n-th table size of the reference (0-based), 0 beyond the list's 450 entries
+uint64_t ref_table_size(int n) {
+    if (n < 0 || n >= 450) return 0;
+    if (n < 10) { uint64_t p = (uint64_t)(n + 1) * 100000; do p++; while (!is_prime64(p)); return p; }
+    const int x = n - 10 + 10;                                       // position counted from mantissa 17 of exponent 0: the list starts at mantissa 27
+    const int e = x / 15, mant = 17 + x % 15;
+    uint64_t p = ((uint64_t)mant << e) * 65536ull;
+    for (;;) { p++; if ((p & 3) == 3 && is_prime64(p) && is_prime64((p - 1) / 2)) return p; }
+}
+void ref_table_sizes(uint64_t value, uint64_t* next, uint64_t* prev) {      // findNextPrime / findPreviousPrime (hashTable.cpp:243-254, :303-314)
+    uint64_t last = 0, before = 0;
+    for (int n = 0; n < 450; n++) { before = last; last = ref_table_size(n); if (last > value || n == 449) break; }
+    *next = last; *prev = before;                                    // (value <= 100003: the reference indexes [-1]; the caller refuses)
+}
+}  // namespace
+int sage2ov_hashtable_save(sage2ov_ctx* c, const char* path) {
+    if (!c || !path) return SAGE2OV_ERR_ARG;
+    if (!c->organized) return c->fail(SAGE2OV_ERR_ARG, "organise (or load) the reads first");
+    const uint64_t N = c->N; const int S = c->S; const int h = c->cfg.min_overlap > 64 ? 64 : (int)c->cfg.min_overlap;
+    if (8 * N <= 100003) return c->fail(SAGE2OV_ERR_LIMIT, "P.hashTable: fewer than 12501 unique reads (the reference's own table-size look-up is undefined there, hashTable.cpp:309-313)");
+    uint64_t M, Mprev; ref_table_sizes(8 * N, &M, &Mprev);
+    if (M <= 8 * N) return c->fail(SAGE2OV_ERR_LIMIT, "P.hashTable: more reads than the reference's largest table holds");
+    const uint64_t pre = ((0xFFFFFFFFFFFFFFFFull) % M + 1) % M;                        // hashTable.cpp:85
+    // the four keys of a read (hashTable.cpp:96-104) as (v0, v1) of utils.cpp:171-187
+    auto take = [](const uint64_t* w, int nw, int a, int n) -> uint64_t { return n <= 0 ? 0ull : (bits64_host(w, nw, 2 * a) >> (64 - 2 * n)); };
+    auto key_of = [&](const uint64_t* w, int nw, int a, uint64_t& v0, uint64_t& v1) { if (h <= 32) { v0 = 0; v1 = take(w, nw, a, h); } else { v0 = take(w, nw, a, h - 32); v1 = take(w, nw, a + h - 32, 32); } };
+    struct Slot { uint64_t v0, v1; int64_t head, tail; uint32_t count; };
+    std::vector<Slot> slot(M + 1, Slot{0, 0, -1, -1, 0});                              // (index M is reachable: `while (p > M)`, hashTable.cpp:163)
+    std::vector<uint64_t> entVal; std::vector<int64_t> entNext; entVal.reserve(4 * N); entNext.reserve(4 * N);
+    for (uint64_t i = 1; i <= N; i++) {                                                // hashTable.cpp:94-109: serial, ids ascending, types 0..3
+        const int L = c->len[i], nw = (L + 31) / 32; uint64_t f[18], r[18];
+        for (int q = 0; q < nw; q++) f[q] = c->words[i * S + q];
+        if (nw == S) f[nw - 1] &= ~SLOT_LEN_MASK;
+        f[nw] = 0; revcomp_words(f, nw, L, r); r[nw] = 0;
+        uint64_t kv[4][2];
+        key_of(f, nw + 1, 0, kv[0][0], kv[0][1]); key_of(f, nw + 1, L - h, kv[1][0], kv[1][1]);
+        key_of(r, nw + 1, 0, kv[2][0], kv[2][1]); key_of(r, nw + 1, L - h, kv[3][0], kv[3][1]);
+        for (int t = 0; t < 4; t++) {
+            const uint64_t v0 = kv[t][0], v1 = kv[t][1];
+            const uint64_t probe = ((v1 % M) + (v0 % M) * pre) % M, inc = 1 + ((v0 + v1) % Mprev);   // :233, :140
+            uint64_t pp = probe, miss = 0;
+            while (slot[pp].head >= 0 && !(slot[pp].v1 == v1 && slot[pp].v0 == v0)) { miss++; pp = probe + miss * inc; while (pp > M) pp -= M; }
+            Slot& sl = slot[pp];
+            if (sl.head < 0 || sl.count <= HASH_THRESHOLD) {                           // :168-186: at most 101 entries
+                const int64_t e = (int64_t)entVal.size(); entVal.push_back(i * 4 + (uint64_t)t); entNext.push_back(-1);
+                if (sl.head < 0) { sl.head = e; sl.v0 = v0; sl.v1 = v1; } else entNext[sl.tail] = e;
+                sl.tail = e; sl.count++;
+            }
+        }
+    }
+    FILE* fo = fopen(path, "w"); if (!fo) return c->fail(SAGE2OV_ERR_IO, std::string("cannot open ") + path);
+    std::vector<char> io(1 << 22); setvbuf(fo, io.data(), _IOFBF, io.size());
+    fprintf(fo, "%llu\n", (unsigned long long)M);
+    const uint64_t longHash = N + 100;                                                 // :77, :111-123
+    int rc = write_formatted(c, fo, M, 24, [&](uint64_t x, std::string& o) {            // hashTable.cpp:12-20 per slot + the "\n" of :268
+        const Slot& sl = slot[x];
+        if (sl.head < 0) { o.append("0\n"); return; }
+        char buf[64]; char* q = put_u(buf, sl.count); *q++ = '\n'; o.append(buf, (size_t)(q - buf));
+        bool first = true;
+        for (int64_t e = sl.head; e >= 0; e = entNext[e]) {
+            const uint64_t id = (first && sl.count >= HASH_THRESHOLD) ? longHash : (entVal[e] >> 2); first = false;
+            q = put_u(buf, id); *q++ = '\t'; q = put_u(q, entVal[e] & 3); *q++ = '\t'; o.append(buf, (size_t)(q - buf));
+        }
+        o.push_back('\n');
+    });
+    fclose(fo); return rc;
+}
+
 // ------------------------------------------------------------------------------------------ step 3
 int sage2ov_shard_range(const sage2ov_ctx* c, uint64_t* lo, uint64_t* hi) {
     if (!c || !lo || !hi) return SAGE2OV_ERR_ARG;

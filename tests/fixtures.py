@@ -13,7 +13,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def golden_names_all():
     """every fixture the reference binary produced (oracle/make_golden.py), including the ones pinned by md5 + size only"""
-    return sorted(os.path.basename(p)[:-5] for p in glob.glob(os.path.join(GOLDEN, "*.json")) if not p.endswith(".step4.json") and not p.endswith("_digest.json"))
+    return sorted(os.path.basename(p)[:-5] for p in glob.glob(os.path.join(GOLDEN, "*.json")) if not p.endswith(".step4.json") and not p.endswith("_digest.json") and not p.endswith(".hashtable.json"))
 
 
 def golden_names():
