@@ -40,7 +40,7 @@ typedef unsigned int u32;
 
 enum { WS_SLOTS, WS_CNT, WS_WHERE, WS_BIG, WS_CSR, WS_SLOW, WS_NEED, WS_DEG, WS_OFFS, WS_CURSOR, WS_KEYS, WS_KEEP, WS_POS, WS_OWNER, WS_FINAL,
        WS_PARTIAL, WS_IDS, WS_NEAR, WS_HITS, WS_MINH, WS_OCNT, WS_OOFF, WS_OCUR, WS_ORDER, WS_MI1, WS_MICNT, WS_MICUR, WS_KREC, WS_SLOTMH, WS_RA_DEG, WS_RA_OFF, WS_RA_CUR, WS_RA_ENT, WS_RA_RM, WS_ORG_POOL, WS_ORG_OFF, WS_ORG_LEN, WS_ORG_IMG, WS_ORG_K0, WS_ORG_K1, WS_ORG_V0, WS_ORG_V1, WS_ORG_HIST, WS_ORG_HSCAN, WS_ORG_FLAG, WS_ORG_UID, WS_ORG_HEAD, WS_RR_IN, WS_RR_DEGP, WS_RR_OFFP, WS_RR_ENTP, WS_RR_OUTP, WS_RR_WIDX, WS_RR_RANK, WS_RR_CUR, WS_RA_HEAVY, WS_RA_HSIZE, WS_RA_HSCR, WS_RR_LEN, WS_RR_COFF, WS_RR_OUTC,
-       WS_PT_K0, WS_PT_K1, WS_PT_P0, WS_PT_P1, WS_PT_M0, WS_PT_M1, WS_PT_CNT, WS_PT_BASE, WS_PT_OFF, WS_PT_GOFF, WS_RR_LOC, WS_RR_RANKL, WS_LOC_READS, WS_LOC_IDOF, WS_LOC_POSOF, WS_LOC_STATUS, WS_COUNT };   // ids of the workspace arena (Device::ws)
+       WS_PT_K0, WS_PT_K1, WS_PT_P0, WS_PT_P1, WS_PT_M0, WS_PT_M1, WS_PT_CNT, WS_PT_BASE, WS_PT_OFF, WS_PT_GOFF, WS_RR_LOC, WS_RR_RANKL, WS_LOC_READS, WS_LOC_IDOF, WS_LOC_POSOF, WS_LOC_STATUS, WS_ORG_GFLAG, WS_ORG_GPOS, WS_COUNT };   // ids of the workspace arena (Device::ws)
 struct Device {
     int ordinal = 0;
     hipStream_t stream = nullptr;
@@ -167,22 +167,43 @@ static int partition_by_window(Device* d, PtBufs& B, bool hasP, bool hasM, u32 n
 // Step 1 on the device: see k_org_canon.  On return the read store is resident exactly as after dev_upload_reads, and the
 // host receives the image (for the .reads writer, lengths) and the frequencies.
 int dev_organize_reads(Device* d, const uint64_t* pool, uint64_t pool_words, const uint64_t* off, const uint16_t* len, uint64_t n, int S, int minL, int maxL, int k,
-                       uint64_t* N_out, std::vector<uint64_t>& words_out, std::vector<uint16_t>& freq_out, std::string& err) {
+                       uint64_t* N_out, std::vector<uint64_t>& words_out, std::vector<uint16_t>& freq_out, std::string& err, OrgAscii* ascii) {
     HIPCHK(hipSetDevice(d->ordinal));
-    if (S != 4 && S != 8 && S != 16) { err = "unsupported words-per-read (read length limit is 504 bases)"; return SAGE2OV_ERR_LIMIT; }
-    if (n >= (1ull << 32) - RS_TILE) { err = "too many reads for the device organiser"; return SAGE2OV_ERR_LIMIT; }
     hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
     HIPCHK(hipEventRecord(e0, d->stream));
+    // ASCII input (sage2ov_reads_add_ascii): filter, 2-bit pack and canonical orientation on the device (utils.cpp:144-166, :96-119, readLoader.cpp:195)
+    unsigned char* dbases = nullptr; u64* doffA = nullptr; u32* gflag = nullptr; u32* gpos = nullptr;
+    if (ascii) {
+        const u64 nin = ascii->n_in;
+        if (nin >= (1ull << 32) - RS_TILE) { err = "too many reads for the device organiser"; return SAGE2OV_ERR_LIMIT; }
+        WS(db, unsigned char, WS_ORG_POOL, ascii->nbytes + 64); WS(dof, u64, WS_ORG_OFF, nin + 2); WS(gf, u32, WS_ORG_GFLAG, nin + 2); WS(gp, u32, WS_ORG_GPOS, nin + 2);
+        dbases = db; doffA = dof; gflag = gf; gpos = gp;
+        HIPCHK(hipMemcpyAsync(dbases, ascii->bases, ascii->nbytes, hipMemcpyHostToDevice, d->stream));
+        HIPCHK(hipMemcpyAsync(doffA, ascii->off, (nin + 1) * sizeof(u64), hipMemcpyHostToDevice, d->stream));
+        u64 init[6] = {0, 0, 0, 0, ~0ull, 0}; HIPCHK(hipMemcpyAsync(d->d_counters + 16, init, sizeof init, hipMemcpyHostToDevice, d->stream));
+        if (nin) hipLaunchKernelGGL(k_org_classify, dim3(grid_for(nin, 256)), dim3(256), 0, d->stream, dbases, doffA, (u64)nin, (u32)k, 504u, gflag, d->d_counters + 16);
+        u64 cc[6]; HIPCHK(hipMemcpyAsync(cc, d->d_counters + 16, sizeof cc, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
+        if (cc[5]) { err = "reads longer than 504 bases are not supported"; return SAGE2OV_ERR_LIMIT; }
+        ascii->good = cc[1]; ascii->total_bp = cc[2]; ascii->small = cc[3]; ascii->maxL = (int)cc[0]; ascii->minL = cc[1] ? (int)cc[4] : 0;
+        n = cc[1]; maxL = ascii->maxL; minL = ascii->minL;
+        { int need = (2 * std::max(maxL, 1) + 9 + 63) / 64; S = 4; while (S < need) S *= 2; } ascii->S = S;
+        if (nin) { u64 tot = 0; int rc = scan_u32(d, gflag, nin, gpos, &tot, err); if (rc) return rc; }
+    }
+    if (S != 4 && S != 8 && S != 16) { err = "unsupported words-per-read (read length limit is 504 bases)"; return SAGE2OV_ERR_LIMIT; }
+    if (n >= (1ull << 32) - RS_TILE) { err = "too many reads for the device organiser"; return SAGE2OV_ERR_LIMIT; }
     u64 N = 0;
     u64* reads = nullptr; unsigned short* dfreq = nullptr;
     if (n) {
-        WS(dpool, u64, WS_ORG_POOL, pool_words + 17); WS(doff, u64, WS_ORG_OFF, n); WS(dlen, unsigned short, WS_ORG_LEN, n);
         WS(img, u64, WS_ORG_IMG, n * S); WS(k0, u64, WS_ORG_K0, n); WS(k1, u64, WS_ORG_K1, n); WS(v0, u32, WS_ORG_V0, n); WS(v1, u32, WS_ORG_V1, n);
-        HIPCHK(hipMemcpyAsync(dpool, pool, pool_words * sizeof(u64), hipMemcpyHostToDevice, d->stream));
-        HIPCHK(hipMemsetAsync(dpool + pool_words, 0, 17 * sizeof(u64), d->stream));
-        HIPCHK(hipMemcpyAsync(doff, off, n * sizeof(u64), hipMemcpyHostToDevice, d->stream));
-        HIPCHK(hipMemcpyAsync(dlen, len, n * sizeof(uint16_t), hipMemcpyHostToDevice, d->stream));
-        hipLaunchKernelGGL(k_org_canon, dim3(grid_for(n, 256)), dim3(256), 0, d->stream, dpool, doff, dlen, (u64)n, S, img, k0, v0);
+        if (ascii) hipLaunchKernelGGL(k_org_pack, dim3(grid_for(ascii->n_in, 256)), dim3(256), 0, d->stream, dbases, doffA, (u64)ascii->n_in, gflag, gpos, S, img, k0, v0);
+        else {
+            WS(dpool, u64, WS_ORG_POOL, pool_words + 17); WS(doff, u64, WS_ORG_OFF, n); WS(dlen, unsigned short, WS_ORG_LEN, n);
+            HIPCHK(hipMemcpyAsync(dpool, pool, pool_words * sizeof(u64), hipMemcpyHostToDevice, d->stream));
+            HIPCHK(hipMemsetAsync(dpool + pool_words, 0, 17 * sizeof(u64), d->stream));
+            HIPCHK(hipMemcpyAsync(doff, off, n * sizeof(u64), hipMemcpyHostToDevice, d->stream));
+            HIPCHK(hipMemcpyAsync(dlen, len, n * sizeof(uint16_t), hipMemcpyHostToDevice, d->stream));
+            hipLaunchKernelGGL(k_org_canon, dim3(grid_for(n, 256)), dim3(256), 0, d->stream, dpool, doff, dlen, (u64)n, S, img, k0, v0);
+        }
         const u32 nb = (u32)((n + RS_TILE - 1) / RS_TILE);
         WS(hist, u32, WS_ORG_HIST, (u64)256 * nb + 2); WS(hscan, u32, WS_ORG_HSCAN, (u64)256 * nb + 2);
         u64 *ka = k0, *kb = k1; u32 *va = v0, *vb = v1;

@@ -66,6 +66,9 @@ struct sage2ov_ctx {
     Device* dev = nullptr;
     // ---- step 1 staging: variable-length word-packed canonical reads
     std::vector<uint64_t> pool; std::vector<uint64_t> poolOff; std::vector<uint16_t> poolLen;
+    // ... or, for ASCII handed over through sage2ov_reads_add_ascii on a GPU context, the raw bases: filter, 2-bit pack and canonical orientation
+    // then run on the device (utils.cpp:144-166, :96-119; readLoader.cpp:195) when the reads are organised
+    std::vector<char> ascii; std::vector<uint64_t> asciiOff;
     uint64_t totalReads = 0, goodReads = 0, totalBP = 0, smallReads = 0;
     std::vector<uint32_t> replayDense;                 // scratch of the host replay (read id -> dense index), all zero between calls
     // ---- organised reads (host copy, ids 1..N)
@@ -497,6 +500,14 @@ void sage2ov_ctx_destroy(sage2ov_ctx* c) { if (!c) return; if (c->dev) dev_destr
 int sage2ov_reads_add_ascii(sage2ov_ctx* c, const char* bases, const uint64_t* off, uint64_t n) {
     if (!c || !bases || !off) return SAGE2OV_ERR_ARG;
     if (c->organized) return c->fail(SAGE2OV_ERR_ARG, "reads already organised");
+    if (c->dev && !getenv("SAGE2OV_HOST_PACK") && !getenv("SAGE2OV_HOST_ORGANIZE")) {        // staged as they come: the device filters and packs them
+        if (c->asciiOff.empty()) c->asciiOff.push_back(0);
+        const uint64_t base = c->ascii.size(), first = off[0], bytes = off[n] - first;
+        c->ascii.insert(c->ascii.end(), bases + first, bases + first + bytes);
+        for (uint64_t r = 1; r <= n; r++) c->asciiOff.push_back(base + (off[r] - first));
+        c->totalReads += n;
+        return SAGE2OV_OK;
+    }
     std::vector<uint8_t> codes;
     for (uint64_t r = 0; r < n; r++) {
         const int L = (int)(off[r + 1] - off[r]); codes.resize(L);
@@ -578,6 +589,25 @@ int sage2ov_reads_organize(sage2ov_ctx* c) {                                    
     if (!c) return SAGE2OV_ERR_ARG;
     if (c->organized) return c->fail(SAGE2OV_ERR_ARG, "reads already organised");
     const int nthr = io_threads(c);                                                   // (clauses, not omp_set_num_threads: a library call must not change the host's OpenMP state)
+    if (!c->asciiOff.empty() && !c->poolLen.empty()) {                                // both kinds of input staged: pack the ASCII here and organise one pool
+        std::vector<uint8_t> codes; const uint64_t na = c->asciiOff.size() - 1;
+        for (uint64_t r = 0; r < na; r++) { const int L = (int)(c->asciiOff[r + 1] - c->asciiOff[r]); codes.resize(L); for (int i = 0; i < L; i++) codes[i] = g_code[(unsigned char)c->ascii[c->asciiOff[r] + i]];
+            stage_codes(c, codes.data(), L, c->pool, c->poolOff, c->poolLen, c->goodReads, c->totalBP, c->smallReads); }
+        std::vector<char>().swap(c->ascii); std::vector<uint64_t>().swap(c->asciiOff);
+    }
+    if (!c->asciiOff.empty()) {                                                       // ASCII only: step 1 entirely on the device
+        OrgAscii A{c->ascii.data(), c->ascii.size(), c->asciiOff.data(), c->asciiOff.size() - 1};
+        uint64_t N = 0;
+        int rc = dev_organize_reads(c->dev, nullptr, 0, nullptr, nullptr, 0, 0, 0, 0, (int)c->cfg.min_overlap, &N, c->words, c->freq, c->err, &A);
+        if (rc) return rc;
+        c->goodReads += A.good; c->totalBP += A.total_bp; c->smallReads += A.small; c->maxL = A.maxL; c->S = A.S;
+        c->N = N; c->len.assign(N + 1, 0);
+        #pragma omp parallel for num_threads(nthr)
+        for (uint64_t i = 1; i <= N; i++) c->len[i] = (uint16_t)(c->words[i * c->S + c->S - 1] & SLOT_LEN_MASK);
+        std::vector<char>().swap(c->ascii); std::vector<uint64_t>().swap(c->asciiOff);
+        c->organized = true; c->indexBuilt = c->probed = c->reciprocalDone = c->reduced = c->converted = false;
+        return SAGE2OV_OK;
+    }
     const uint64_t n = c->poolLen.size();
     int maxL = 0; for (uint64_t i = 0; i < n; i++) maxL = std::max<int>(maxL, c->poolLen[i]);
     c->maxL = maxL; c->S = choose_S(std::max(maxL, 1));

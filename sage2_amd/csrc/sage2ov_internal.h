@@ -61,8 +61,10 @@ int dev_unresolved_hits(Device* d, std::vector<Hit>& hits, uint64_t* n_unresolve
 int dev_download_status(Device* d, std::vector<uint8_t>& status, std::string& err);
 int dev_unresolved_ids(Device* d, std::vector<uint32_t>& ids, std::string& err);          // ascending
 int dev_collect_reduce_edges(Device* d, std::vector<EdgeCand>& out, std::string& err);
+// ASCII input of step 1 (sage2ov_reads_add_ascii): raw bases + offsets in, filter / pack / canonical orientation on the device; the counters come back
+struct OrgAscii { const char* bases; uint64_t nbytes; const uint64_t* off; uint64_t n_in; uint64_t good = 0, total_bp = 0, small = 0; int maxL = 0, minL = 0, S = 0; };
 int dev_organize_reads(Device* d, const uint64_t* pool, uint64_t pool_words, const uint64_t* off, const uint16_t* len, uint64_t n, int S, int minL, int maxL, int k,
-                       uint64_t* N_out, std::vector<uint64_t>& words_out, std::vector<uint16_t>& freq_out, std::string& err);
+                       uint64_t* N_out, std::vector<uint64_t>& words_out, std::vector<uint16_t>& freq_out, std::string& err, OrgAscii* ascii = nullptr);
 int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved, uint64_t* n_hits, uint64_t* inserted, uint64_t* removed, int* done, std::string& err);
 // append host-computed edge candidates (from the reduce replay) to the device candidate list
 int dev_debug_table(Device* d, uint64_t* out5, std::string& err);

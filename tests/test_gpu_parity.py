@@ -690,3 +690,44 @@ def test_long_bucket_reduce_in_many_slices(monkeypatch):
         st = ctx.overlap_stats(); res[mode] = (ctx.edges().tobytes(), st.edges_inserted, st.transitive_removed, st.left_to_explore)
         ctx.close(); monkeypatch.delenv("SAGE2OV_TEST_RANK_SLICE", raising=False)
     assert res["sliced"][1:] == res["host"][1:] and res["sliced"][0] == res["host"][0]
+
+
+def test_device_filter_and_pack_of_ascii_input(monkeypatch):
+    """sage2ov_reads_add_ascii on a GPU context hands the RAW bases to the device: isGoodRead (utils.cpp:144-166: longer than minOverlap, only
+    ACGTacgt, lower case accepted), charsToBytes (utils.cpp:96-119) and the canonical orientation (readLoader.cpp:195) run there.  Lower-case
+    reads, reads with N / other characters, reads not longer than k and mixed lengths, in several batches -- counters, ids, lengths, frequencies and
+    packed bytes against the host path of the same library (SAGE2OV_HOST_PACK) and against the oracle."""
+    pd = dict(seed=77, genome_len=30000, n_reads=14000, read_len=120, read_len_min=30, err_ppm=1000)
+    bases, off = fx.make_reads(pd)
+    seqs = [bytes(bases[int(off[i]):int(off[i + 1])]) for i in range(len(off) - 1)]
+    rng = np.random.default_rng(5)
+    for i in range(0, len(seqs), 7):
+        seqs[i] = seqs[i].lower()                                            # accepted, upper-cased
+    for i in range(3, len(seqs), 97):
+        s = bytearray(seqs[i]); s[int(rng.integers(0, len(s)))] = ord("N"); seqs[i] = bytes(s)      # dropped
+    for i in range(5, len(seqs), 211):
+        s = bytearray(seqs[i]); s[-1] = ord("x"); seqs[i] = bytes(s)                               # dropped (bad last character)
+    flat = np.frombuffer(b"".join(seqs), dtype=np.uint8).copy()
+    o2 = np.zeros(len(seqs) + 1, dtype=np.uint64); o2[1:] = np.cumsum([len(s) for s in seqs])
+    k = 35                                                                    # reads of 30..35 bases are "small"
+    res = {}
+    for mode in ("device", "host"):
+        if mode == "host":
+            monkeypatch.setenv("SAGE2OV_HOST_PACK", "1")
+        else:
+            monkeypatch.delenv("SAGE2OV_HOST_PACK", raising=False)
+        c = s2.Context(k, device=0)
+        third = len(seqs) // 3                                                # three batches: offsets of later batches do not start at 0
+        for a, b in ((0, third), (third, 2 * third), (2 * third, len(seqs))):
+            c.reads_add_ascii(flat, o2[a:b + 1])
+        c.reads_organize(); st = c.reads_stats()
+        res[mode] = (c.reads_export(), (st.total_reads, st.good_reads, st.unique_reads, st.total_bp, st.max_read_length, st.words_per_read), c)
+    (dp, dl, df), dst, dc = res["device"]; (hp, hl, hf), hst, hc = res["host"]
+    assert dst == hst and dst[0] == len(seqs) and dst[1] < len(seqs)
+    assert np.array_equal(dl, hl) and np.array_equal(df, hf) and np.array_equal(dp, hp)
+    o = ol.Oracle(k, 8); o.add_reads_ascii(flat, o2); o.organize()
+    op, ol_, of = o.export_reads(); w = min(dp.shape[1], op.shape[1])
+    assert (o.counter("total_reads"), o.counter("good_reads"), o.counter("N"), o.counter("total_bp")) == dst[:4]
+    assert np.array_equal(dl, ol_) and np.array_equal(df, of) and np.array_equal(dp[:, :w - 1], op[:, :w - 1])
+    dc.run_steps23(); o.run_all(); assert_equals_oracle(dc, o)
+    dc.close(); hc.close(); o.close()
