@@ -84,3 +84,39 @@ extern "C" int sage2ref_run_step4(const char* in_prefix, int k, int threads, con
     logStream.close();
     return 0;
 }
+
+// The in-memory hand-over of INTEGRATION.md section 2: the reference's OWN graph object is filled from a canonical edge list (what
+// sage2ov_edges_export returns) through its own insertEdgeInGraph (overlapGraph.cpp:120), in list order -- the order convertGraph would have
+// produced (overlapGraph.cpp:93-111) -- and then runs ITS step 4 (main.cpp:150-172) and ITS writer.  If the hand-over is right, the dump is the
+// graph4 fixture (made from the reference's own files).  edges: n x {from, to, type, length} u64.
+extern "C" int sage2ref_step4_from_edges(const char* reads_path, int k, int threads, const unsigned long long* edges, unsigned long long n,
+                                         unsigned long long good_reads, unsigned long long avg_len, const char* out_graph4, unsigned long long* c /* [4] */) {
+    if (threads > 0) omp_set_num_threads(threads);
+    if (logStream.is_open()) logStream.close();
+    logStream.open((std::string(out_graph4) + ".log").c_str());
+    genomeSize = 0; averageReadLength = avg_len;                                   // (what loadOverlapGraphFromFile takes from the graph3 header, overlapGraph.cpp:382-385)
+    ReadLoader* loader = new ReadLoader((uint16_t)k);
+    loader->loadReadsFromFile(reads_path);                                         // main.cpp:144
+    loader->numberOfReads = good_reads;
+    OverlapGraph* graph = new OverlapGraph(loader);                                // main.cpp:146
+    for (unsigned long long x = 0; x < n; x++)
+        graph->insertEdgeInGraph(edges[4 * x], edges[4 * x + 1], (uint32_t)edges[4 * x + 3], (uint8_t)edges[4 * x + 2]);      // overlapGraph.cpp:101-108
+    int threshold = 0, closeValue = 10;
+    unsigned long long contracted = 0, removed = 0, iters = 0;
+    contracted += contractCompositePaths(graph, loader);
+    removed += removeDeadEnds(graph, loader, threshold);
+    removed += removeBubbles(graph, loader, closeValue);
+    contracted += contractCompositePaths(graph, loader);
+    for (;;) {
+        uint64_t a = removeDeadEnds(graph, loader, threshold), b = removeBubbles(graph, loader, closeValue), cc = contractCompositePaths(graph, loader);
+        removed += a + b; contracted += cc; iters++;
+        if (a + b + cc == 0) break;
+        if (closeValue < 50) closeValue += 10;
+        if (threshold < 3) threshold++;
+    }
+    graph->saveOverlapGraphInFile(out_graph4);
+    c[0] = loader->numberOfUniqueReads; c[1] = iters; c[2] = contracted; c[3] = removed;
+    delete graph; delete loader;
+    logStream.close();
+    return 0;
+}

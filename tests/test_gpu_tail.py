@@ -49,3 +49,31 @@ def test_reference_tail_on_gpu_written_files(name, start, tmp_path):
     for sfx in suffixes:
         assert _same(os.path.join(ours, "t2" + sfx), os.path.join(full, "t" + sfx)), f"{name} from step {start}: {sfx} differs"
     shutil.rmtree(ours, ignore_errors=True); shutil.rmtree(full, ignore_errors=True)
+
+
+@pytest.mark.parametrize("name", ["g1_clean100_k21", "g3_noisy_rep_k21", "g4_highcopy_k21", "g5_mixedlen_k21", "g6_k70_150"])
+def test_in_memory_handover_to_the_references_classes(name, tmp_path):
+    """INTEGRATION.md section 2, compiled and run: the canonical edge list the GPU computed (sage2ov_edges_export) is fed to the REFERENCE's own
+    OverlapGraph::insertEdgeInGraph in list order (oracle/ref_driver.cpp::sage2ref_step4_from_edges, linked against the reference's objects), the
+    reference runs ITS step 4 on that in-memory graph and dumps it with ITS writer: the result must be the graph4 fixture, which the reference
+    produced from its own P.graph3 -- i.e. handing the edges over in memory is equivalent to going through the file."""
+    import ctypes as C, gzip
+    import numpy as np
+    drv = os.path.join(fx.ROOT, "oracle", "_ref", "libsage2ref_driver.so")
+    if not os.path.exists(drv):
+        pytest.skip("oracle/_ref not built")
+    L = C.CDLL(drv)
+    if not hasattr(L, "sage2ref_step4_from_edges"):
+        pytest.skip("oracle/_ref is older than this test: rebuild it in the build container (make -C oracle ref)")
+    m = fx.golden(name)
+    bases, off = fx.make_reads(m["synth"])
+    ctx = s2.Context(m["k"], device=0); ctx.reads_add_ascii(bases, off); ctx.reads_organize(); ctx.run_steps23()
+    rp = str(tmp_path / "t.reads"); ctx.reads_save(rp)
+    e = ctx.edges(); st = ctx.reads_stats()
+    flat = np.stack([e["from"], e["to"], e["type"].astype(np.uint64), e["length"].astype(np.uint64)], axis=1).astype(np.uint64).copy()
+    out = str(tmp_path / "t.graph4"); c = (C.c_ulonglong * 4)()
+    L.sage2ref_step4_from_edges.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_ulonglong, C.c_ulonglong, C.c_ulonglong, C.c_char_p, C.POINTER(C.c_ulonglong)]
+    assert L.sage2ref_step4_from_edges(rp.encode(), m["k"], 4, flat.ctypes.data, len(e), st.good_reads, st.average_read_length, out.encode(), c) == 0
+    want = gzip.open(os.path.join(fx.GOLDEN, name + ".graph4.gz"), "rb").read()
+    assert open(out, "rb").read() == want
+    ctx.close()
