@@ -40,7 +40,7 @@ typedef unsigned int u32;
 
 enum { WS_SLOTS, WS_CNT, WS_WHERE, WS_BIG, WS_CSR, WS_SLOW, WS_NEED, WS_DEG, WS_OFFS, WS_CURSOR, WS_KEYS, WS_KEEP, WS_POS, WS_OWNER, WS_FINAL,
        WS_PARTIAL, WS_IDS, WS_NEAR, WS_HITS, WS_MINH, WS_OCNT, WS_OOFF, WS_OCUR, WS_ORDER, WS_MI1, WS_MICNT, WS_MICUR, WS_KREC, WS_SLOTMH, WS_RA_DEG, WS_RA_OFF, WS_RA_CUR, WS_RA_ENT, WS_RA_RM, WS_ORG_POOL, WS_ORG_OFF, WS_ORG_LEN, WS_ORG_IMG, WS_ORG_K0, WS_ORG_K1, WS_ORG_V0, WS_ORG_V1, WS_ORG_HIST, WS_ORG_HSCAN, WS_ORG_FLAG, WS_ORG_UID, WS_ORG_HEAD, WS_RR_IN, WS_RR_DEGP, WS_RR_OFFP, WS_RR_ENTP, WS_RR_OUTP, WS_RR_WIDX, WS_RR_RANK, WS_RR_CUR, WS_RA_HEAVY, WS_RA_HSIZE, WS_RA_HSCR, WS_RR_LEN, WS_RR_COFF, WS_RR_OUTC,
-       WS_PT_K0, WS_PT_K1, WS_PT_P0, WS_PT_P1, WS_PT_M0, WS_PT_M1, WS_PT_CNT, WS_PT_BASE, WS_PT_OFF, WS_PT_GOFF, WS_RR_LOC, WS_RR_RANKL, WS_LOC_READS, WS_LOC_IDOF, WS_LOC_POSOF, WS_LOC_STATUS, WS_ORG_GFLAG, WS_ORG_GPOS, WS_COUNT };   // ids of the workspace arena (Device::ws)
+       WS_PT_K0, WS_PT_K1, WS_PT_P0, WS_PT_P1, WS_PT_M0, WS_PT_M1, WS_PT_CNT, WS_PT_BASE, WS_PT_OFF, WS_PT_GOFF, WS_RR_LOC, WS_RR_RANKL, WS_LOC_READS, WS_LOC_IDOF, WS_LOC_POSOF, WS_LOC_STATUS, WS_ORG_GFLAG, WS_ORG_GPOS, WS_LOC_META, WS_COUNT };   // ids of the workspace arena (Device::ws)
 struct Device {
     int ordinal = 0;
     hipStream_t stream = nullptr;
@@ -50,7 +50,7 @@ struct Device {
     u64* reads = nullptr;        // (N+1)*S words, slot i = read id i
     // the same reads in LOCALITY order (slot p = the read at position p of the order by global minimiser): what the index entries point at and
     // what the probe kernels gather from -- a read's overlap partners are neighbours in the genome, hence (mostly) neighbours here
-    u64* readsLoc = nullptr; u32* idOf = nullptr; u32* posOf = nullptr; uint8_t* statusP = nullptr;
+    u64* readsLoc = nullptr; u32* idOf = nullptr; u32* posOf = nullptr; uint8_t* statusP = nullptr; unsigned short* metaP = nullptr;
     // index
     u64 T = 0; u64* slots = nullptr; u32* csr = nullptr; u64 n_csr = 0; u64 seed = 0x5A6E2D0Full;
     u64 n_keys = 0, n_long = 0;
@@ -263,16 +263,16 @@ int dev_organize_reads(Device* d, const uint64_t* pool, uint64_t pool_words, con
     return 0;
 }
 
-static int build_locality_order(Device* d, u64 lo, u64 hi, u32** order_out, std::string& err);
+static int build_locality_order(Device* d, u64 lo, u64 hi, const u64** order_out, std::string& err);
 // The locality-ordered copy of the read store + the two translation tables (see Device::readsLoc).  Part of the index build (timed with it).
-__global__ void k_loc_store(const u64* __restrict__ reads, const u32* __restrict__ order, u64 N, int S, u64* out, u32* idOf, u32* posOf) {
+__global__ void k_loc_store(const u64* __restrict__ reads, const u64* __restrict__ order, u64 N, int S, u64* out, u32* idOf, u32* posOf, unsigned short* meta) {
     const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t < (u64)S) out[t] = 0ull;                                                      // slot 0: zeros (the target of gated-off gathers)
-    if (t == 0) { idOf[0] = 0; posOf[0] = 0; idOf[N + 1] = 0; posOf[N + 1] = 0; }
+    if (t == 0) { idOf[0] = 0; posOf[0] = 0; idOf[N + 1] = 0; posOf[N + 1] = 0; meta[0] = 0xFFFF; meta[N + 1] = 0xFFFF; }
     if (t >= N * S) return;
-    const u64 p = t / S; const int c = (int)(t % S); const u32 id = order ? order[p] : (u32)(p + 1);
+    const u64 p = t / S; const int c = (int)(t % S); const u64 o = order ? order[p] : (u64)(p + 1) | (0xFFFFull << 32); const u32 id = (u32)o;
     out[(p + 1) * S + c] = reads[(u64)id * S + c];
-    if (c == 0) { idOf[p + 1] = id; posOf[id] = (u32)(p + 1); }
+    if (c == 0) { idOf[p + 1] = id; posOf[id] = (u32)(p + 1); meta[p + 1] = (unsigned short)(o >> 32); }   // meta 0xFFFF: no minimiser information (no window reuse)
 }
 __global__ void k_status_by_pos(const u32* __restrict__ idOf, const uint8_t* __restrict__ status, u64 N, uint8_t* statusP) {
     const u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x; if (p > N) return; statusP[p] = p ? status[idOf[p]] : (uint8_t)0xFF;
@@ -281,10 +281,11 @@ __global__ void k_ids_to_pos(const u32* __restrict__ ids, u64 n, const u32* __re
 static int build_locality_store(Device* d, std::string& err) {
     const u64 N = d->N;
     WS(rl, u64, WS_LOC_READS, (N + 1) * d->S); WS(io, u32, WS_LOC_IDOF, N + 2); WS(po, u32, WS_LOC_POSOF, N + 2); WS(sp, uint8_t, WS_LOC_STATUS, N + 2);
-    d->readsLoc = rl; d->idOf = io; d->posOf = po; d->statusP = sp;
-    u32* order = nullptr;
+    WS(me, unsigned short, WS_LOC_META, N + 2);
+    d->readsLoc = rl; d->idOf = io; d->posOf = po; d->statusP = sp; d->metaP = me;
+    const u64* order = nullptr;
     if (N && !getenv("SAGE2OV_NO_LOCALITY")) { int rc = build_locality_order(d, 1, N + 1, &order, err); if (rc) return rc; }
-    hipLaunchKernelGGL(k_loc_store, dim3(grid_for(std::max<u64>(N * d->S, d->S), 256)), dim3(256), 0, d->stream, d->reads, order, (u64)N, d->S, rl, io, po);
+    hipLaunchKernelGGL(k_loc_store, dim3(grid_for(std::max<u64>(N * d->S, d->S), 256)), dim3(256), 0, d->stream, d->reads, order, (u64)N, d->S, rl, io, po, me);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -462,27 +463,32 @@ static int launch_probe(Device* d, ProbeArgs& A, std::string& err) {
 }
 static int scan_u32(Device* d, const u32* in, u64 n, u32* out, u64* total, std::string& err);
 // processing order of ids [lo,hi): grouped by the reads' global minimiser (see k_minimizer)
-static int build_locality_order(Device* d, u64 lo, u64 hi, u32** order_out, std::string& err) {
+static int build_locality_order(Device* d, u64 lo, u64 hi, const u64** order_out, std::string& err) {
     const u64 n = hi - lo;
-    // reads sorted by the top bits of their global minimiser's hash (two radix passes, kernels_partition.inc; the order inside a bucket
-    // of equal top bits is free): 18 bits or one bucket per ~16 reads, whichever is coarser
-    // 27 bits of the hash (three passes): reads with one minimiser end up next to each other -- measured at BASELINE configs[2]: probe kernel
-    // 149 -> 142 ms from the finer processing order alone, 120 ms with the read store in that order too
+    // reads sorted by (top bits of their global minimiser's hash, strand of the minimiser, start of the read relative to it): LSD radix passes
+    // (kernels_partition.inc), first the 9 bits of strand + offset, then 27 bits of the hash (three passes) -- reads with one minimiser end up next to each
+    // other, each starting a few bases after the one before.  Measured at BASELINE configs[2]: probe kernel 149 -> 142 ms from the finer processing
+    // order alone, 120 ms with the read store in that order too.  *order_out: per position, meta << 32 | id.
     int lg = 27;
     if (const char* ev = getenv("SAGE2OV_ORDER_BITS")) lg = std::max(1, std::min(32, atoi(ev)));
     const u32 ntiles = (u32)((n + PT_TILE - 1) / PT_TILE);
-    PtBufs B; B.P[0] = B.P[1] = nullptr;
+    PtBufs B; B.M[0] = B.M[1] = nullptr;
     { WS(a, u32, WS_MINH, n + 4); B.K[0] = a; } { WS(a, u32, WS_OCUR, n + 4); B.K[1] = a; }
-    { WS(a, u32, WS_ORDER, n + 4); B.M[0] = a; } { WS(a, u32, WS_OOFF, n + 4); B.M[1] = a; }
+    { WS(a, u64, WS_ORDER, n + 4); B.P[0] = a; } { WS(a, u64, WS_OOFF, n + 4); B.P[1] = a; }
+    WS(mh, u32, WS_OCNT, n + 4); WS(mt, u32, WS_MICNT, n + 4);
     WS(cnt, u32, WS_PT_CNT, (u64)PT_NB_MAX * std::max<u32>(ntiles, 1) + 2); WS(base, u32, WS_PT_BASE, (u64)PT_NB_MAX * std::max<u32>(ntiles, 1) + 2);
-    hipLaunchKernelGGL(k_minimizer, dim3(grid_for(n, 256)), dim3(256), 0, d->stream, d->reads, (u64)lo, (u64)hi, d->S, B.K[0], B.M[0]);
-    int cur = 0; int rc = partition_by_window(d, B, false, true, (u32)n, 32 - lg, 1ull << lg, false, cnt, base, nullptr, &cur, err); if (rc) return rc;
-    *order_out = B.M[cur];
+    hipLaunchKernelGGL(k_minimizer, dim3(grid_for(n, 256)), dim3(256), 0, d->stream, d->reads, (u64)lo, (u64)hi, d->S, mh, mt);
+    hipLaunchKernelGGL(k_order_pack, dim3(grid_for(n, 256)), dim3(256), 0, d->stream, mh, mt, (u64)n, (u64)lo, B.K[0], B.P[0]);
+    int cur = 0; int rc = partition_by_window(d, B, true, false, (u32)n, 0, 1ull << 9, false, cnt, base, nullptr, &cur, err); if (rc) return rc;
+    PtBufs C; C.M[0] = C.M[1] = nullptr; C.K[0] = B.K[cur ^ 1]; C.P[0] = B.P[cur ^ 1]; C.K[1] = B.K[cur]; C.P[1] = B.P[cur];
+    hipLaunchKernelGGL(k_order_rekey, dim3(grid_for(n, 256)), dim3(256), 0, d->stream, B.K[cur], B.P[cur], (u64)n, C.K[0], C.P[0]);
+    int cur2 = 0; rc = partition_by_window(d, C, true, false, (u32)n, 32 - lg, 1ull << lg, false, cnt, base, nullptr, &cur2, err); if (rc) return rc;
+    *order_out = C.P[cur2];
     return 0;
 }
 static ProbeArgs base_args(Device* d) {
     ProbeArgs A; memset(&A, 0, sizeof A);
-    A.reads = d->readsLoc; A.idOf = d->idOf; A.statusP = d->statusP; A.N = d->N; A.S = d->S; A.k = d->k; A.h = d->h; A.slots = d->slots; A.T = d->T; A.csr = d->csr; A.seed = d->seed;
+    A.reads = d->readsLoc; A.idOf = d->idOf; A.statusP = d->statusP; A.meta = getenv("SAGE2OV_NO_WINDOW_REUSE") ? nullptr : d->metaP; A.N = d->N; A.S = d->S; A.k = d->k; A.h = d->h; A.slots = d->slots; A.T = d->T; A.csr = d->csr; A.seed = d->seed;
     A.right = d->right; A.left = d->left; A.conn = d->conn; A.cflag = d->cflag; A.status = d->status; A.counters = d->d_counters;
     A.mi1 = d->mi1; A.TL = d->TL; A.krec = d->krec; A.uniL = d->uniL;
     return A;
@@ -523,8 +529,8 @@ int dev_probe(Device* d, uint64_t lo, uint64_t hi, std::string& err) {
         const unsigned blocks = (unsigned)std::min<u64>((nreads + FAST_CHUNK - 1) / FAST_CHUNK, 256ull * 16);
 #ifdef SAGE2OV_STAMPS
         static u64* d_stamps = nullptr;
-        if (!d_stamps) HIPCHK(hipMalloc(&d_stamps, 10 * sizeof(u64)));
-        HIPCHK(hipMemsetAsync(d_stamps, 0, 10 * sizeof(u64), d->stream)); A.stamps = d_stamps;
+        if (!d_stamps) HIPCHK(hipMalloc(&d_stamps, 16 * sizeof(u64)));
+        HIPCHK(hipMemsetAsync(d_stamps, 0, 16 * sizeof(u64), d->stream)); A.stamps = d_stamps;
 #endif
         HIPCHK(hipEventRecord(d->ev[2], d->stream));
         const bool launched = launch_fast_any<0>(d, A, blocks);               // false: 16-word layout, sequential kernel only (for now)
@@ -537,8 +543,9 @@ int dev_probe(Device* d, uint64_t lo, uint64_t hi, std::string& err) {
         float ms = 0; hipEventElapsedTime(&ms, d->ev[2], d->ev[3]); d->tm.probe_kernel_ms += ms; d->tm.probe_launches++;
         d->tm.slow_reads += nslow;
 #ifdef SAGE2OV_STAMPS
-        { u64 st[10]; HIPCHK(hipMemcpy(st, d_stamps, sizeof st, hipMemcpyDeviceToHost)); u64 tot = 0; for (u64 v : st) tot += v;
-          fprintf(stderr, "[stamps] kernel %.2f ms; share of wave cycles:", ms); for (int x = 0; x < 10; x++) fprintf(stderr, " %d:%.1f%%", x, 100.0 * (double)st[x] / (double)tot); fprintf(stderr, "\n"); }
+        { u64 st[16]; HIPCHK(hipMemcpy(st, d_stamps, sizeof st, hipMemcpyDeviceToHost)); u64 tot = 0; for (int x = 0; x < 10; x++) tot += st[x];
+          fprintf(stderr, "[stamps] kernel %.2f ms; share of wave cycles:", ms); for (int x = 0; x < 10; x++) fprintf(stderr, " %d:%.1f%%", x, 100.0 * (double)st[x] / (double)tot);
+          fprintf(stderr, "; window reuse: %llu of %llu reads (same minimiser strand as the previous read: %llu), mean shift %.1f\n", (unsigned long long)st[11], (unsigned long long)st[10], (unsigned long long)st[13], st[11] ? (double)st[12] / (double)st[11] : 0.0); }
 #endif
         if (nslow) {                                                          // ambiguous / overflowing reads: sequential state machine
             ProbeArgs B = base_args(d); B.ids = slow; B.n_ids = nslow;
