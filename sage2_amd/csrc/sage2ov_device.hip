@@ -335,6 +335,7 @@ static void pt_first_digit(u64 nWin, int shiftW, int* shift0, u32* mask0, int* d
 int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t* csr_out, uint64_t* nlong_out, uint32_t* rebuilds, std::string& err) {
     HIPCHK(hipSetDevice(d->ordinal));
     const u64 N = d->N; if (!d->reads) { err = "reads not resident"; return SAGE2OV_ERR_ARG; }
+    HIPCHK(hipEventRecord(d->ev[0], d->stream));                          // (the locality store is part of the build and of index_ms)
     { int rc = build_locality_store(d, err); if (rc) return rc; }
     d->T = std::max<u64>(IX_W, (8 * N + IX_W - 1) / IX_W * IX_W);            // load <= 0.5, as hashTable.cpp:83 sizes it; whole windows
     if (d->T >= (1ull << 32)) { err = "table too large for 32-bit slot indices"; return SAGE2OV_ERR_LIMIT; }
@@ -360,7 +361,6 @@ int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t
         WS(kr_, u64, WS_KREC, 4 * N + MI_SCAN_PAD); krec = kr_;              // one record per distinct key (<= 4N)
         WS(go, u32, WS_PT_GOFF, gW + 3); gOff = go;
     }
-    HIPCHK(hipEventRecord(d->ev[0], d->stream));
     *rebuilds = 0;
     const bool timing = getenv("SAGE2OV_TIMING") != nullptr; auto tp = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) { if (!timing) return; hipStreamSynchronize(d->stream); auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[index] %-34s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - tp).count()); tp = t; };
