@@ -731,3 +731,30 @@ def test_device_filter_and_pack_of_ascii_input(monkeypatch):
     assert np.array_equal(dl, ol_) and np.array_equal(df, of) and np.array_equal(dp[:, :w - 1], op[:, :w - 1])
     dc.run_steps23(); o.run_all(); assert_equals_oracle(dc, o)
     dc.close(); hc.close(); o.close()
+
+
+def test_index_heavy_windows_match_oracle():
+    """One key in 70 000 reads (all start with the same 25 bases) and one in 5 000: the table windows those keys land in hold far more tuples than a
+    workgroup keeps in registers (3 072) resp. than the LDS-staged bucket order can index (65 535), so the build takes its global-scratch paths
+    (k_ix_window: surplus tuples through `wh`, CSR segment written and ordered in global memory by id) and the purity check walks a 70 000-entry
+    bucket.  Results against the oracle: bucket contents in order, long-bucket count, extension records, edges."""
+    rng = np.random.default_rng(123)
+    L, k = 100, 25
+    def rnd(n): return "".join(rng.choice(list("ACGT"), size=n))
+    p1, p2 = rnd(25), rnd(25)
+    reads = [p1 + rnd(L - 25) for _ in range(70000)] + [p2 + rnd(L - 25) for _ in range(5000)]
+    genome = rnd(60000)
+    reads += [genome[s:s + L] for s in rng.integers(0, len(genome) - L, size=30000)]
+    bases = np.frombuffer("".join(reads).encode(), dtype=np.uint8).copy()
+    off = np.arange(0, (len(reads) + 1) * L, L, dtype=np.uint64)
+    m = dict(k=k)
+    g, o = run_gpu(m, bases, off), run_oracle(m, bases, off)
+    assert g.reads_stats().unique_reads == o.counter("N")
+    assert g.index_stats().long_buckets == o.counter("long_buckets") >= 2
+    fwd, ln, _ = o.export_reads()
+    for rid in rng.integers(1, len(ln), 300):                                   # sampled keys, incl. suffix keys of the heavy reads (short buckets in heavy windows)
+        for start in (0, int(ln[rid]) - k):
+            want, wn = o.lookup(0, ol.get64(bytes(fwd[rid]), start, k)); got, gn = g.index_lookup(0, ol.get64(bytes(fwd[rid]), start, k))
+            assert gn == wn and got == want[:len(got)]
+    assert_equals_oracle(g, o)
+    g.close(); o.close()
