@@ -338,7 +338,9 @@ int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t
     HIPCHK(hipEventRecord(d->ev[0], d->stream));                          // (the locality store is part of the build and of index_ms)
     { int rc = build_locality_store(d, err); if (rc) return rc; }
     d->T = std::max<u64>(IX_W, (8 * N + IX_W - 1) / IX_W * IX_W);            // load <= 0.5, as hashTable.cpp:83 sizes it; whole windows
-    if (d->T >= (1ull << 32)) { err = "table too large for 32-bit slot indices"; return SAGE2OV_ERR_LIMIT; }
+    // (tests: SAGE2OV_TEST_TABLE_SLOTS forces a larger table, e.g. beyond 2^32 slots -- slot indices are 64-bit, pair indices and window ids 32-bit)
+    if (const char* ev = getenv("SAGE2OV_TEST_TABLE_SLOTS")) { const u64 want = strtoull(ev, nullptr, 10); if (want > d->T) d->T = (want + IX_W - 1) / IX_W * IX_W; }
+    if ((d->T >> 1) >= (1ull << 32)) { err = "table too large: more than 2^32 slot pairs"; return SAGE2OV_ERR_LIMIT; }
     const u64 nW = d->T / IX_W; const u32 n = (u32)(4 * N);
     const u32 big_cap = 1u << 20;
     WS(slots_ws, u64, WS_SLOTS, d->T); d->slots = slots_ws;

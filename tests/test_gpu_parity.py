@@ -758,3 +758,24 @@ def test_index_heavy_windows_match_oracle():
             assert gn == wn and got == want[:len(got)]
     assert_equals_oracle(g, o)
     g.close(); o.close()
+
+
+def test_table_beyond_2_to_32_slots(monkeypatch):
+    """BASELINE configs[4] (1.2 G reads, about 1.0 G unique) needs 8 N = 8.2 G slots: slot indices are 64-bit everywhere (pair indices and window ids
+    stay below 2^32 up to 2^33 slots).  Exercised here by forcing a table of 2^32 + 2^20 slots (34 GB of HBM, written once by the window kernel)
+    under a small read set: index contents, extension records and edges against the oracle."""
+    monkeypatch.setenv("SAGE2OV_TEST_TABLE_SLOTS", str((1 << 32) + (1 << 20)))
+    pd = dict(seed=91, genome_len=60000, n_reads=30000, read_len=150, err_ppm=500)
+    bases, off = fx.make_reads(pd)
+    m = dict(k=40)
+    g, o = run_gpu(m, bases, off), run_oracle(m, bases, off)
+    assert g.index_stats().slots >= (1 << 32) + (1 << 20) and g.index_stats().keys == o.counter("keys")
+    fwd, ln, _ = o.export_reads()
+    rng = np.random.default_rng(3)
+    for rid in rng.integers(1, len(ln), 200):
+        for start in (0, int(ln[rid]) - 40):
+            b = bytes(fwd[rid]); v0, v1 = ol.get64(b, start, 8), ol.get64(b, start + 8, 32)
+            want, wn = o.lookup(v0, v1); got, gn = g.index_lookup(v0, v1)
+            assert gn == wn and got == want[:len(got)]
+    assert_equals_oracle(g, o)
+    g.close(); o.close()
