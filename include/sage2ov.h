@@ -209,10 +209,12 @@ int sage2ov_shard_edges_set(sage2ov_ctx* ctx, const void* dev_src, uint64_t n_ed
 /* ---- profiling hooks: HIP-event timings of the last run, milliseconds ---- */
 typedef struct sage2ov_timings {
     double index_ms, probe_ms, reciprocal_ms, reduce_ms, convert_ms, total_ms;
-    double probe_kernel_ms;      /* the dominant kernel alone (HIP events on the context stream) */
-    uint64_t probe_kernel_launches;
+    double probe_kernel_ms;      /* the dominant kernel alone (HIP events on the context stream), summed over its launches */
+    uint64_t probe_kernel_launches;   /* probe PASSES timed (one per initial pass): probe_kernel_ms / this = kernel time per pass */
     uint64_t sequential_reads;   /* reads the fast kernel handed to the sequential state-machine kernel */
     double organize_ms;          /* step 1 on the device: upload of the staged reads .. organised read store resident (HIP events) */
+    uint64_t probe_fast_launches;     /* launches of the fast kernel behind probe_kernel_ms: a pass is a sample launch, the rest of the range
+                                         and, if reads were listed, one launch over the list */
 } sage2ov_timings;
 int sage2ov_timings_get(const sage2ov_ctx* ctx, sage2ov_timings* out);
 int sage2ov_timings_reset(sage2ov_ctx* ctx);

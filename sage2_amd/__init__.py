@@ -48,7 +48,7 @@ class SimplifyStats(C.Structure):
 class Timings(C.Structure):
     _fields_ = [("index_ms", C.c_double), ("probe_ms", C.c_double), ("reciprocal_ms", C.c_double), ("reduce_ms", C.c_double),
                 ("convert_ms", C.c_double), ("total_ms", C.c_double), ("probe_kernel_ms", C.c_double), ("probe_kernel_launches", C.c_uint64), ("sequential_reads", C.c_uint64),
-                ("organize_ms", C.c_double)]
+                ("organize_ms", C.c_double), ("probe_fast_launches", C.c_uint64)]
 
 
 class SynthParams(C.Structure):

@@ -40,7 +40,7 @@ typedef unsigned int u32;
 
 enum { WS_SLOTS, WS_CNT, WS_WHERE, WS_BIG, WS_CSR, WS_SLOW, WS_NEED, WS_DEG, WS_OFFS, WS_CURSOR, WS_KEYS, WS_KEEP, WS_POS, WS_OWNER, WS_FINAL,
        WS_PARTIAL, WS_IDS, WS_NEAR, WS_HITS, WS_MINH, WS_OCNT, WS_OOFF, WS_OCUR, WS_ORDER, WS_MI1, WS_MICNT, WS_MICUR, WS_KREC, WS_SLOTMH, WS_RA_DEG, WS_RA_OFF, WS_RA_CUR, WS_RA_ENT, WS_RA_RM, WS_ORG_POOL, WS_ORG_OFF, WS_ORG_LEN, WS_ORG_IMG, WS_ORG_K0, WS_ORG_K1, WS_ORG_V0, WS_ORG_V1, WS_ORG_HIST, WS_ORG_HSCAN, WS_ORG_FLAG, WS_ORG_UID, WS_ORG_HEAD, WS_RR_IN, WS_RR_DEGP, WS_RR_OFFP, WS_RR_ENTP, WS_RR_OUTP, WS_RR_WIDX, WS_RR_RANK, WS_RR_CUR, WS_RA_HEAVY, WS_RA_HSIZE, WS_RA_HSCR, WS_RR_LEN, WS_RR_COFF, WS_RR_OUTC,
-       WS_PT_K0, WS_PT_K1, WS_PT_P0, WS_PT_P1, WS_PT_M0, WS_PT_M1, WS_PT_CNT, WS_PT_BASE, WS_PT_OFF, WS_PT_GOFF, WS_RR_LOC, WS_RR_RANKL, WS_LOC_READS, WS_LOC_IDOF, WS_LOC_POSOF, WS_LOC_STATUS, WS_ORG_GFLAG, WS_ORG_GPOS, WS_LOC_META, WS_COUNT };   // ids of the workspace arena (Device::ws)
+       WS_PT_K0, WS_PT_K1, WS_PT_P0, WS_PT_P1, WS_PT_M0, WS_PT_M1, WS_PT_CNT, WS_PT_BASE, WS_PT_OFF, WS_PT_GOFF, WS_RR_LOC, WS_RR_RANKL, WS_LOC_READS, WS_LOC_IDOF, WS_LOC_POSOF, WS_LOC_STATUS, WS_ORG_GFLAG, WS_ORG_GPOS, WS_LOC_META, WS_SLOW2, WS_COUNT };   // ids of the workspace arena (Device::ws)
 struct Device {
     int ordinal = 0;
     hipStream_t stream = nullptr;
@@ -496,22 +496,23 @@ static ProbeArgs base_args(Device* d) {
     return A;
 }
 
-template <int S, int NW, int WPL, int WPB, int HITS = 0>
-static void launch_fast(Device* d, ProbeArgs& A, unsigned blocks) { hipLaunchKernelGGL((k_probe_fast<S, NW, WPL, WPB, HITS>), dim3(blocks), dim3(64 * WPB), 0, d->stream, A); }
+template <int S, int NW, int WPL, int WPB, int HITS, int TAIL>
+static void launch_fast(Device* d, ProbeArgs& A, unsigned blocks) { hipLaunchKernelGGL((k_probe_fast<S, NW, WPL, WPB, HITS, TAIL>), dim3(blocks), dim3(64 * WPB), 0, d->stream, A); }
 // picks the instantiation for the resident reads; false: the 16-word layout has no fast kernel
-template <int HITS>
+template <int HITS, int TAIL>
 static bool launch_fast_any(Device* d, ProbeArgs& A, unsigned blocks) {
     constexpr int FW = SAGE2OV_FAST_WPB;      // waves per block: a whole CU's worth works on one locality chunk
     const int nwinMax = d->maxL - d->h + 1;                               // windows of the longest read
-    if (d->S == 4 && nwinMax <= 128) launch_fast<4, 8, 2, FW, HITS>(d, A, blocks);
-    else if (d->S == 8 && d->maxL <= 160 && nwinMax <= 128) launch_fast<8, 10, 2, FW, HITS>(d, A, blocks);
-    else if (d->S == 8 && d->maxL <= 160) launch_fast<8, 10, 3, FW, HITS>(d, A, blocks);      // 129..160 windows, e.g. 150-bp reads with k <= 22
+    if (d->S == 4 && nwinMax <= 128) launch_fast<4, 8, 2, FW, HITS, TAIL>(d, A, blocks);
+    else if (d->S == 8 && d->maxL <= 160 && nwinMax <= 128) launch_fast<8, 10, 2, FW, HITS, TAIL>(d, A, blocks);
+    else if (d->S == 8 && d->maxL <= 160) launch_fast<8, 10, 3, FW, HITS, TAIL>(d, A, blocks);      // 129..160 windows, e.g. 150-bp reads with k <= 22
     // (the 16-dword layout's state-machine rows take 12 KB of LDS per wave: four waves per block keep three blocks on a CU)
-    else if (d->S == 8 && nwinMax <= 128) launch_fast<8, 16, 2, (HITS ? FW : 4), HITS>(d, A, blocks);
-    else if (d->S == 8) launch_fast<8, 16, 4, (HITS ? FW : 4), HITS>(d, A, blocks);
+    else if (d->S == 8 && nwinMax <= 128) launch_fast<8, 16, 2, ((HITS || !TAIL) ? FW : 4), HITS, TAIL>(d, A, blocks);
+    else if (d->S == 8) launch_fast<8, 16, 4, ((HITS || !TAIL) ? FW : 4), HITS, TAIL>(d, A, blocks);
     else return false;
     return true;
 }
+static unsigned fast_blocks(u64 n) { return (unsigned)std::min<u64>((n + FAST_CHUNK - 1) / FAST_CHUNK, 256ull * 16); }
 
 int dev_probe(Device* d, uint64_t lo, uint64_t hi, std::string& err) {
     HIPCHK(hipSetDevice(d->ordinal));
@@ -528,29 +529,74 @@ int dev_probe(Device* d, uint64_t lo, uint64_t hi, std::string& err) {
         WS(slow, u32, WS_SLOW, nreads);
         A.slow = slow; A.slow_cap = nreads;
         // (positions [lo, hi) of the locality order: consecutive items are neighbours in the genome AND in the read store)
-        const unsigned blocks = (unsigned)std::min<u64>((nreads + FAST_CHUNK - 1) / FAST_CHUNK, 256ull * 16);
 #ifdef SAGE2OV_STAMPS
         static u64* d_stamps = nullptr;
-        if (!d_stamps) HIPCHK(hipMalloc(&d_stamps, 16 * sizeof(u64)));
-        HIPCHK(hipMemsetAsync(d_stamps, 0, 16 * sizeof(u64), d->stream)); A.stamps = d_stamps;
+        if (!d_stamps) HIPCHK(hipMalloc(&d_stamps, 24 * sizeof(u64)));
+        HIPCHK(hipMemsetAsync(d_stamps, 0, 24 * sizeof(u64), d->stream)); A.stamps = d_stamps;
 #endif
-        HIPCHK(hipEventRecord(d->ev[2], d->stream));
-        const bool launched = launch_fast_any<0>(d, A, blocks);               // false: 16-word layout, sequential kernel only (for now)
-        if (!launched) { int rc = launch_probe<0>(d, A, err); if (rc) return rc; }
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipEventRecord(d->ev[3], d->stream));
-        u64 nslow = 0;
-        if (launched) HIPCHK(hipMemcpyAsync(&nslow, d->d_counters + 6, sizeof nslow, hipMemcpyDeviceToHost, d->stream));
-        HIPCHK(hipStreamSynchronize(d->stream));
-        float ms = 0; hipEventElapsedTime(&ms, d->ev[2], d->ev[3]); d->tm.probe_kernel_ms += ms; d->tm.probe_launches++;
+        // Which kernel?  The one that carries the state machine for inconsistent reads (TAIL = 1) is 10 % slower on every read; on error-free
+        // data a read in a thousand needs it.  So the first 1/32 of the range runs without it (TAIL = 0: such reads are listed), the share of
+        // listed reads decides for the rest, and the listed reads go through the TAIL = 1 kernel as an id list afterwards; what that one
+        // cannot settle either (more than 128 candidates, overhangs beyond its rows) ends in the sequential kernel, as before.
+        const char* evs = getenv("SAGE2OV_PROBE_SAMPLE_MIN");                 // tests: sample on small inputs too
+        const u64 sampleMin = evs ? strtoull(evs, nullptr, 10) : (256u << 10);
+        const char* evt = getenv("SAGE2OV_PROBE_TAIL");                       // "0" / "1": no sampling, that kernel for everything
+        u64 nsample = (nreads >= 2 * sampleMin && !evt) ? std::max<u64>(nreads / 32, sampleMin) : 0;
+        nsample = (nsample + FAST_CHUNK - 1) / FAST_CHUNK * FAST_CHUNK;
+        bool tailKernel = evt ? atoi(evt) != 0 : true, anyListed = evt && !tailKernel;
+        bool launched = true;
+        u64 nslow = 0; float kms = 0;
+        auto timed = [&](auto&& launch) -> int {                              // one launch of the fast kernel between two events
+            HIPCHK(hipEventRecord(d->ev[2], d->stream));
+            launch();
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipEventRecord(d->ev[3], d->stream));
+            HIPCHK(hipMemcpyAsync(&nslow, d->d_counters + 6, sizeof nslow, hipMemcpyDeviceToHost, d->stream));
+            HIPCHK(hipStreamSynchronize(d->stream));
+            float ms = 0; hipEventElapsedTime(&ms, d->ev[2], d->ev[3]); kms += ms; d->tm.probe_fast_launches++;
+            if (getenv("SAGE2OV_TIMING")) fprintf(stderr, "[probe] fast kernel launch %.3f ms, listed so far %llu\n", ms, (unsigned long long)nslow);
+            return 0;
+        };
+        if (nsample && nsample < nreads) {
+            ProbeArgs As = A; As.hi = lo + nsample;
+            int rc = timed([&] { launched = launch_fast_any<0, 0>(d, As, fast_blocks(nsample)); }); if (rc) return rc;
+            if (launched) {
+                anyListed = true;
+                tailKernel = nslow * 32 > nsample;                            // more than 3 % listed: the data are noisy
+                ProbeArgs Ar = A; Ar.lo = lo + nsample;
+                rc = timed([&] { if (tailKernel) launch_fast_any<0, 1>(d, Ar, fast_blocks(nreads - nsample)); else launch_fast_any<0, 0>(d, Ar, fast_blocks(nreads - nsample)); }); if (rc) return rc;
+            }
+        } else {
+            int rc = timed([&] { launched = tailKernel ? launch_fast_any<0, 1>(d, A, fast_blocks(nreads)) : launch_fast_any<0, 0>(d, A, fast_blocks(nreads)); }); if (rc) return rc;
+        }
+        if (!launched) {                                                       // 16-word layout: sequential kernel only (for now)
+            HIPCHK(hipEventRecord(d->ev[2], d->stream));
+            int rc = launch_probe<0>(d, A, err); if (rc) return rc;
+            HIPCHK(hipEventRecord(d->ev[3], d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
+            float ms = 0; hipEventElapsedTime(&ms, d->ev[2], d->ev[3]); kms += ms; nslow = 0;
+        }
+        u32* list = slow;
+        if (launched && anyListed && nslow) {                                  // listed by the TAIL = 0 kernel: the state machine, in the TAIL = 1 kernel
+            WS(slow2, u32, WS_SLOW2, nslow);
+            HIPCHK(hipMemsetAsync(d->d_counters + 6, 0, sizeof(u64), d->stream));
+            ProbeArgs B = base_args(d); B.ids = slow; B.n_ids = nslow; B.slow = slow2; B.slow_cap = nslow;
+#ifdef SAGE2OV_STAMPS
+            B.stamps = A.stamps;
+#endif
+            const u64 nl = nslow;
+            int rc = timed([&] { launch_fast_any<0, 1>(d, B, fast_blocks(nl)); }); if (rc) return rc;
+            list = slow2;
+        }
+        d->tm.probe_kernel_ms += kms; d->tm.probe_launches++;
         d->tm.slow_reads += nslow;
 #ifdef SAGE2OV_STAMPS
-        { u64 st[16]; HIPCHK(hipMemcpy(st, d_stamps, sizeof st, hipMemcpyDeviceToHost)); u64 tot = 0; for (int x = 0; x < 10; x++) tot += st[x];
-          fprintf(stderr, "[stamps] kernel %.2f ms; share of wave cycles:", ms); for (int x = 0; x < 10; x++) fprintf(stderr, " %d:%.1f%%", x, 100.0 * (double)st[x] / (double)tot);
+        { u64 st[24]; HIPCHK(hipMemcpy(st, d_stamps, sizeof st, hipMemcpyDeviceToHost)); u64 tot = 0; for (int x = 0; x < 24; x++) if (x < 10 || x >= 16) tot += st[x];
+          // stages 0-9 in order of the code; 16 = slot -> window -> entry (before the gathers), 17 = reach, 18 = broadcast of the speculated reads, 19 = compares (8 = what follows them)
+          fprintf(stderr, "[stamps] kernel %.2f ms; share of wave cycles (cycles per read):", kms); for (int x = 0; x < 24; x++) if (x < 10 || (x >= 16 && x < 21)) fprintf(stderr, " %d:%.1f%% (%.0f)", x, 100.0 * (double)st[x] / (double)tot, st[10] ? (double)st[x] / (double)st[10] : 0.0);
           fprintf(stderr, "; window reuse: %llu of %llu reads (same minimiser strand as the previous read: %llu), mean shift %.1f\n", (unsigned long long)st[11], (unsigned long long)st[10], (unsigned long long)st[13], st[11] ? (double)st[12] / (double)st[11] : 0.0); }
 #endif
-        if (nslow) {                                                          // ambiguous / overflowing reads: sequential state machine
-            ProbeArgs B = base_args(d); B.ids = slow; B.n_ids = nslow;
+        if (launched && nslow) {                                              // ambiguous / overflowing reads: sequential state machine
+            ProbeArgs B = base_args(d); B.ids = list; B.n_ids = nslow;
             int rc = launch_probe<0>(d, B, err); if (rc) return rc;
         }
     } else if (nreads) {
@@ -919,7 +965,7 @@ int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved
             ProbeArgs A = base_args(d); A.lo = 1; A.hi = N + 1; A.hits = dh; A.hits_cap = cap; A.hitcount = hitcount;
             A.slow = slow; A.slow_cap = N + 1;                                       // (all positions; the kernel skips what is not status 0)
             u64 c3[3] = {0, 0, 0};
-            if (launch_fast_any<1>(d, A, blocks)) {
+            if (launch_fast_any<1, 0>(d, A, blocks)) {
                 HIPCHK(hipGetLastError());
                 HIPCHK(hipMemcpyAsync(c3, d->d_counters + 4, sizeof c3, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
                 if (c3[0] > cap) { cap = c3[0] + c3[0] / 8 + 1024; continue; }            // some chunk did not fit: everything again

@@ -1128,7 +1128,7 @@ int sage2ov_timings_get(const sage2ov_ctx* c, sage2ov_timings* o) {
     if (!c || !o) return SAGE2OV_ERR_ARG;
     DevTimings t; if (c->dev) dev_timings(c->dev, &t);
     o->index_ms = t.index_ms; o->probe_ms = t.probe_ms; o->reciprocal_ms = t.reciprocal_ms; o->reduce_ms = c->reduce_ms; o->convert_ms = t.convert_ms;
-    o->total_ms = c->total_ms; o->probe_kernel_ms = t.probe_kernel_ms; o->probe_kernel_launches = t.probe_launches; o->sequential_reads = t.slow_reads; o->organize_ms = t.organize_ms;
+    o->total_ms = c->total_ms; o->probe_kernel_ms = t.probe_kernel_ms; o->probe_kernel_launches = t.probe_launches; o->sequential_reads = t.slow_reads; o->organize_ms = t.organize_ms; o->probe_fast_launches = t.probe_fast_launches;
     return SAGE2OV_OK;
 }
 

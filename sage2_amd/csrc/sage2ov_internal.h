@@ -30,7 +30,7 @@ struct EdgeCand { uint32_t from, to; uint32_t len; uint32_t type; };   // from <
 struct Hit { uint32_t from; uint32_t to; int32_t len; uint16_t seq_hi; uint8_t type; uint8_t pad; uint32_t seq; };
 struct FinalEdge { uint32_t from, to, len, len_twin; uint32_t type; };
 
-struct DevTimings { double index_ms = 0, probe_ms = 0, reciprocal_ms = 0, hits_ms = 0, convert_ms = 0, probe_kernel_ms = 0, organize_ms = 0; uint64_t probe_launches = 0, slow_reads = 0; };
+struct DevTimings { double index_ms = 0, probe_ms = 0, reciprocal_ms = 0, hits_ms = 0, convert_ms = 0, probe_kernel_ms = 0, organize_ms = 0; uint64_t probe_launches = 0, slow_reads = 0, probe_fast_launches = 0; };
 
 struct Device;   // opaque, lives in sage2ov_device.hip
 

@@ -779,3 +779,30 @@ def test_table_beyond_2_to_32_slots(monkeypatch):
             assert gn == wn and got == want[:len(got)]
     assert_equals_oracle(g, o)
     g.close(); o.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["sample", "tail0", "tail1"])
+@pytest.mark.parametrize("pd,k", [
+    (dict(seed=71, genome_len=60000, n_reads=20000, read_len=150, err_ppm=0), 40),                          # clean: the sample keeps the kernel without the state machine
+    (dict(seed=72, genome_len=60000, n_reads=20000, read_len=150, err_ppm=1500), 40),                       # noisy: the sample switches to the kernel with it
+    (dict(seed=73, genome_len=50000, n_reads=16000, read_len=150, read_len_min=90, err_ppm=800), 31),        # mixed lengths (containments), errors
+    (dict(seed=74, genome_len=30000, n_reads=12000, read_len=100, err_ppm=1000, n_repeat_families=4, repeat_len=400, repeat_copies=6), 25),   # repeats: reads past 128 candidates end in the sequential kernel
+    (dict(seed=75, genome_len=40000, n_reads=9000, read_len=250, err_ppm=1000), 45),                        # 16-dword compare
+])
+def test_probe_kernel_choice_is_exact(pd, k, mode, monkeypatch):
+    """dev_probe picks between the fast kernel with the in-kernel state machine for inconsistent reads (TAIL = 1) and the one that lists such
+    reads (TAIL = 0) from a sample of the range; listed reads go through the TAIL = 1 kernel as an id list, its leftovers through the
+    sequential kernel.  Every route gives the oracle's records: the sampled route (forced on a small input), and each kernel alone."""
+    if mode == "sample":
+        monkeypatch.setenv("SAGE2OV_PROBE_SAMPLE_MIN", "2048")
+    else:
+        monkeypatch.setenv("SAGE2OV_PROBE_TAIL", "0" if mode == "tail0" else "1")
+    bases, off = fx.make_reads(pd)
+    m = dict(k=k)
+    g, o = run_gpu(m, bases, off), run_oracle(m, bases, off)
+    assert_equals_oracle(g, o)
+    tm = g.timings()
+    if mode == "sample":
+        assert tm.probe_fast_launches >= 2 * tm.probe_kernel_launches            # a sample launch and the rest, per pass
+    g.close(); o.close()
