@@ -1081,7 +1081,8 @@ int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved
     WS(svn, u32, WS_NEED, nun + 2); WS(svoff, u32, WS_OWNER, nun + 2);
     const unsigned gb = (unsigned)std::min<u64>((nun + 3) / 4, 256ull * 16);
     const u64 heavyCap = 1 << 16; WS(heavy, u32, WS_RA_HEAVY, heavyCap);
-    hipLaunchKernelGGL(k_ra_mark, dim3(gb), dim3(256), 0, d->stream, ids, (u64)nun, offs, deg, ent, rm, svn, d->d_counters + 8, heavy, heavyCap);
+    hipLaunchKernelGGL((k_ra_mark<128, 8, 0, false>), dim3(gb), dim3(256), 0, d->stream, ids, (u64)nun, offs, deg, ent, rm, svn, d->d_counters + 8, heavy, heavyCap);     // lists of <= 128 entries
+    hipLaunchKernelGGL((k_ra_mark<RA_CAP, 10, 128, true>), dim3(gb), dim3(256), 0, d->stream, ids, (u64)nun, offs, deg, ent, rm, svn, d->d_counters + 8, heavy, heavyCap);   // 129 .. RA_CAP; longer: k_ra_mark_big
     u64 c[2];
     HIPCHK(hipMemcpyAsync(c, d->d_counters + 8, sizeof c, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
     HIPCHK(hipGetLastError());
