@@ -543,7 +543,7 @@ int dev_probe(Device* d, uint64_t lo, uint64_t hi, std::string& err) {
         const char* evt = getenv("SAGE2OV_PROBE_TAIL");                       // "0" / "1": no sampling, that kernel for everything
         u64 nsample = (nreads >= 2 * sampleMin && !evt) ? std::max<u64>(nreads / 32, sampleMin) : 0;
         nsample = (nsample + FAST_CHUNK - 1) / FAST_CHUNK * FAST_CHUNK;
-        bool tailKernel = evt ? atoi(evt) != 0 : true, anyListed = evt && !tailKernel;
+        int tailKernel = evt ? atoi(evt) : 1; bool anyListed = evt && tailKernel == 0;       // 0 / 1 / 2: see k_probe_fast
         bool launched = true;
         u64 nslow = 0; float kms = 0;
         auto timed = [&](auto&& launch) -> int {                              // one launch of the fast kernel between two events
@@ -562,12 +562,13 @@ int dev_probe(Device* d, uint64_t lo, uint64_t hi, std::string& err) {
             int rc = timed([&] { launched = launch_fast_any<0, 0>(d, As, fast_blocks(nsample)); }); if (rc) return rc;
             if (launched) {
                 anyListed = true;
-                tailKernel = nslow * 32 > nsample;                            // more than 3 % listed: the data are noisy
-                ProbeArgs Ar = A; Ar.lo = lo + nsample;
-                rc = timed([&] { if (tailKernel) launch_fast_any<0, 1>(d, Ar, fast_blocks(nreads - nsample)); else launch_fast_any<0, 0>(d, Ar, fast_blocks(nreads - nsample)); }); if (rc) return rc;
+                tailKernel = nslow * 2 > nsample ? 2 : (nslow * 32 > nsample ? 1 : 0);   // listed: more than half -> state machine for every read; more than 3 % -> kernel that carries it
+                ProbeArgs Ar = A; Ar.lo = lo + nsample; const unsigned nb = fast_blocks(nreads - nsample);
+                rc = timed([&] { if (tailKernel == 2) launch_fast_any<0, 2>(d, Ar, nb); else if (tailKernel == 1) launch_fast_any<0, 1>(d, Ar, nb); else launch_fast_any<0, 0>(d, Ar, nb); }); if (rc) return rc;
             }
         } else {
-            int rc = timed([&] { launched = tailKernel ? launch_fast_any<0, 1>(d, A, fast_blocks(nreads)) : launch_fast_any<0, 0>(d, A, fast_blocks(nreads)); }); if (rc) return rc;
+            const unsigned nb = fast_blocks(nreads);
+            int rc = timed([&] { launched = tailKernel == 2 ? launch_fast_any<0, 2>(d, A, nb) : (tailKernel == 1 ? launch_fast_any<0, 1>(d, A, nb) : launch_fast_any<0, 0>(d, A, nb)); }); if (rc) return rc;
         }
         if (!launched) {                                                       // 16-word layout: sequential kernel only (for now)
             HIPCHK(hipEventRecord(d->ev[2], d->stream));

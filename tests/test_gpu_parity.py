@@ -782,7 +782,7 @@ def test_table_beyond_2_to_32_slots(monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["sample", "tail0", "tail1"])
+@pytest.mark.parametrize("mode", ["sample", "tail0", "tail1", "tail2"])
 @pytest.mark.parametrize("pd,k", [
     (dict(seed=71, genome_len=60000, n_reads=20000, read_len=150, err_ppm=0), 40),                          # clean: the sample keeps the kernel without the state machine
     (dict(seed=72, genome_len=60000, n_reads=20000, read_len=150, err_ppm=1500), 40),                       # noisy: the sample switches to the kernel with it
@@ -793,11 +793,12 @@ def test_table_beyond_2_to_32_slots(monkeypatch):
 def test_probe_kernel_choice_is_exact(pd, k, mode, monkeypatch):
     """dev_probe picks between the fast kernel with the in-kernel state machine for inconsistent reads (TAIL = 1) and the one that lists such
     reads (TAIL = 0) from a sample of the range; listed reads go through the TAIL = 1 kernel as an id list, its leftovers through the
-    sequential kernel.  Every route gives the oracle's records: the sampled route (forced on a small input), and each kernel alone."""
+    sequential kernel; TAIL = 2 sends every read through the state machine.  Every route gives the oracle's records: the sampled route
+    (forced on a small input), and each kernel alone."""
     if mode == "sample":
         monkeypatch.setenv("SAGE2OV_PROBE_SAMPLE_MIN", "2048")
     else:
-        monkeypatch.setenv("SAGE2OV_PROBE_TAIL", "0" if mode == "tail0" else "1")
+        monkeypatch.setenv("SAGE2OV_PROBE_TAIL", mode[-1])
     bases, off = fx.make_reads(pd)
     m = dict(k=k)
     g, o = run_gpu(m, bases, off), run_oracle(m, bases, off)
