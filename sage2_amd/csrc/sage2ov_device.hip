@@ -535,13 +535,13 @@ int dev_probe(Device* d, uint64_t lo, uint64_t hi, std::string& err) {
         HIPCHK(hipMemsetAsync(d_stamps, 0, 24 * sizeof(u64), d->stream)); A.stamps = d_stamps;
 #endif
         // Which kernel?  The one that carries the state machine for inconsistent reads (TAIL = 1) is 10 % slower on every read; on error-free
-        // data a read in a thousand needs it.  So the first 1/32 of the range runs without it (TAIL = 0: such reads are listed), the share of
+        // data a read in a thousand needs it.  So the first 1/128 of the range runs without it (TAIL = 0: such reads are listed), the share of
         // listed reads decides for the rest, and the listed reads go through the TAIL = 1 kernel as an id list afterwards; what that one
         // cannot settle either (more than 128 candidates, overhangs beyond its rows) ends in the sequential kernel, as before.
         const char* evs = getenv("SAGE2OV_PROBE_SAMPLE_MIN");                 // tests: sample on small inputs too
-        const u64 sampleMin = evs ? strtoull(evs, nullptr, 10) : (256u << 10);
-        const char* evt = getenv("SAGE2OV_PROBE_TAIL");                       // "0" / "1": no sampling, that kernel for everything
-        u64 nsample = (nreads >= 2 * sampleMin && !evt) ? std::max<u64>(nreads / 32, sampleMin) : 0;
+        const u64 sampleMin = evs ? strtoull(evs, nullptr, 10) : (128u << 10);
+        const char* evt = getenv("SAGE2OV_PROBE_TAIL");                       // "0" / "1" / "2": no sampling, that kernel for everything
+        u64 nsample = (nreads >= 4 * sampleMin && !evt) ? std::max<u64>(nreads / 128, sampleMin) : 0;   // (on noisy data the sample is work done twice)
         nsample = (nsample + FAST_CHUNK - 1) / FAST_CHUNK * FAST_CHUNK;
         int tailKernel = evt ? atoi(evt) : 1; bool anyListed = evt && tailKernel == 0;       // 0 / 1 / 2: see k_probe_fast
         bool launched = true;

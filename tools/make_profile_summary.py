@@ -28,14 +28,21 @@ with open(os.path.join(prof, f"{tag}_pmc_summary.txt"), "w") as o:
         if not k.startswith(("s2::", "void s2::")):
             continue
         n = cnt[(k, c)]; o.write(f"{k} {c} {v / n:.6g} {n} {v / n / N:.3f}\n")
-pk = [k for (k, c) in acc if "k_probe_fast" in k]
+# the probe pass of a step is up to three launches of k_probe_fast<..., HITS = 0, TAIL> (sample, rest of the range, listed reads): the figures
+# are per PASS = summed over those launches, divided by the number of steps profiled (= launches of k_ix_window, one per index build)
+import re
+def is_pass_kernel(k):
+    m = re.search(r"k_probe_fast<([^>]*)>", k)
+    return bool(m) and [x.strip() for x in m.group(1).split(",")][4] == "0"
+pk = sorted({k for (k, c) in acc if is_pass_kernel(k)})
 if pk:
-    k = pk[0]
-    f = acc.get((k, "FETCH_SIZE"), 0) / max(cnt.get((k, "FETCH_SIZE"), 1), 1); w = acc.get((k, "WRITE_SIZE"), 0) / max(cnt.get((k, "WRITE_SIZE"), 1), 1)
+    k = " + ".join(pk)
+    def per_launch(c):
+        passes = max(cnt.get(("s2::k_ix_window", c), 0), 1)
+        return sum(acc.get((kk, c), 0) for kk in pk) / passes
+    f = per_launch("FETCH_SIZE"); w = per_launch("WRITE_SIZE")
     # request sizes at the L2's memory side: on gfx950 every read request of this kernel is a 128-byte line (TCC_EA0_RDREQ_128B == TCC_EA0_RDREQ),
     # which FETCH_SIZE tallies at 64 bytes -- the guide's "double it" case; writes are 32-byte requests and WRITE_SIZE counts them exactly
-    def per_launch(c):
-        return acc.get((k, c), 0) / max(cnt.get((k, c), 1), 1)
     r128, r64, r32 = per_launch("TCC_EA0_RDREQ_128B_sum"), per_launch("TCC_EA0_RDREQ_64B_sum"), per_launch("TCC_EA0_RDREQ_32B_sum")
     rd_bytes = (128.0 * r128 + 64.0 * r64 + 32.0 * r32) if r128 else 2.0 * f * 1024.0
     if f:
@@ -46,6 +53,6 @@ if pk:
         key = f"{m.group(1)}x{m.group(2)}_k{m.group(3)}_seed{m.group(4)}"
         cur[key] = {"bytes_per_launch": rd_bytes + w * 1024.0, "read_bytes": rd_bytes, "write_bytes": w * 1024.0, "fetch_KiB_as_reported": f, "write_KiB": w,
                     "read_requests_128B": r128, "kernel": k, "source": f"profiles/{tag}_pmc_summary.txt",
-                    "note": "reads = TCC_EA0_RDREQ_128B x 128 B (all read requests are 128-byte lines; FETCH_SIZE tallies them at 64 B, cf. MI355X_MICROARCH.md HBM section)"}
+                    "note": "per probe pass (sum over the pass's launches of the kernel); reads = TCC_EA0_RDREQ_128B x 128 B (all read requests are 128-byte lines; FETCH_SIZE tallies them at 64 B, cf. MI355X_MICROARCH.md HBM section)"}
         json.dump(cur, open(tj, "w"), indent=1)
 print("ok")
