@@ -39,6 +39,8 @@ FIXTURES = {
     # where the device takes its ranked path by default.  Too big to commit as a file: md5 + size + counters only.
     "g9_repeats160k_k40": (40, 8, dict(seed=9, genome_len=500000, n_reads=160000, read_len=150, err_ppm=1500,
                                        n_repeat_families=6, repeat_copies=250, repeat_len=350)),
+    # reads of 520..900 bases with errors: the 32-word slot layout (505 .. 1018 bases, 11-bit length field), sequential probe kernel only
+    "g10_long900_k55":   (55, 8, dict(seed=10, genome_len=150000, n_reads=16000, read_len=900, read_len_min=520, err_ppm=800)),
     # hand-made input (tests/fixtures.py::recipe_reads): palindromic region, tandem repeat, mirrored duplicates
     "g7_palindrome_tandem_k21": (21, 8, dict(recipe="palindrome_tandem", seed=7, half=700, flank=24000, tandem_units=60, read_len=100, step=3)),
 }

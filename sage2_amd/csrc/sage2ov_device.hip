@@ -146,7 +146,7 @@ void dev_reset_timings(Device* d) { d->tm = DevTimings(); }
 
 int dev_upload_reads(Device* d, const uint64_t* words, uint64_t N, int S, int minL, int maxL, int k, std::string& err) {
     HIPCHK(hipSetDevice(d->ordinal));
-    if (S != 4 && S != 8 && S != 16) { err = "unsupported words-per-read (read length limit is 504 bases)"; return SAGE2OV_ERR_LIMIT; }
+    if (S != 4 && S != 8 && S != 16 && S != 32) { err = "unsupported words-per-read (read length limit is 1018 bases)"; return SAGE2OV_ERR_LIMIT; }
     if (N >= (1ull << 30)) { err = "more than 2^30-1 unique reads per context is not supported yet"; return SAGE2OV_ERR_LIMIT; }
     free_reads(d);
     d->N = N; d->S = S; d->maxL = maxL; d->k = k; d->h = k > 64 ? 64 : k; d->uniL = (N && minL == maxL) ? maxL : 0;
@@ -181,15 +181,15 @@ int dev_organize_reads(Device* d, const uint64_t* pool, uint64_t pool_words, con
         HIPCHK(hipMemcpyAsync(dbases, ascii->bases, ascii->nbytes, hipMemcpyHostToDevice, d->stream));
         HIPCHK(hipMemcpyAsync(doffA, ascii->off, (nin + 1) * sizeof(u64), hipMemcpyHostToDevice, d->stream));
         u64 init[6] = {0, 0, 0, 0, ~0ull, 0}; HIPCHK(hipMemcpyAsync(d->d_counters + 16, init, sizeof init, hipMemcpyHostToDevice, d->stream));
-        if (nin) hipLaunchKernelGGL(k_org_classify, dim3(grid_for(nin, 256)), dim3(256), 0, d->stream, dbases, doffA, (u64)nin, (u32)k, 504u, gflag, d->d_counters + 16);
+        if (nin) hipLaunchKernelGGL(k_org_classify, dim3(grid_for(nin, 256)), dim3(256), 0, d->stream, dbases, doffA, (u64)nin, (u32)k, 1018u, gflag, d->d_counters + 16);
         u64 cc[6]; HIPCHK(hipMemcpyAsync(cc, d->d_counters + 16, sizeof cc, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
-        if (cc[5]) { err = "reads longer than 504 bases are not supported"; return SAGE2OV_ERR_LIMIT; }
+        if (cc[5]) { err = "reads longer than 1018 bases are not supported"; return SAGE2OV_ERR_LIMIT; }
         ascii->good = cc[1]; ascii->total_bp = cc[2]; ascii->small = cc[3]; ascii->maxL = (int)cc[0]; ascii->minL = cc[1] ? (int)cc[4] : 0;
         n = cc[1]; maxL = ascii->maxL; minL = ascii->minL;
         { int need = (2 * std::max(maxL, 1) + 9 + 63) / 64; S = 4; while (S < need) S *= 2; } ascii->S = S;
         if (nin) { u64 tot = 0; int rc = scan_u32(d, gflag, nin, gpos, &tot, err); if (rc) return rc; }
     }
-    if (S != 4 && S != 8 && S != 16) { err = "unsupported words-per-read (read length limit is 504 bases)"; return SAGE2OV_ERR_LIMIT; }
+    if (S != 4 && S != 8 && S != 16 && S != 32) { err = "unsupported words-per-read (read length limit is 1018 bases)"; return SAGE2OV_ERR_LIMIT; }
     if (n >= (1ull << 32) - RS_TILE) { err = "too many reads for the device organiser"; return SAGE2OV_ERR_LIMIT; }
     u64 N = 0;
     u64* reads = nullptr; unsigned short* dfreq = nullptr;
@@ -450,14 +450,15 @@ int dev_lookup(Device* d, uint64_t hi, uint64_t lo, uint64_t* entries, uint32_t 
 template <int MODE>
 static int launch_probe(Device* d, ProbeArgs& A, std::string& err) {
     const u64 nreads = A.ids ? A.n_ids : A.hi - A.lo; if (nreads == 0) return 0;
-    // one wave per read, 4 waves per block (2 for the 16-word layout: LDS); enough blocks to fill
+    // one wave per read, 4 waves per block (2 for the 16-word layout, 1 for the 32-word layout: LDS); enough blocks to fill
     // 256 CUs several times over, grid-stride beyond
-    const unsigned wpb = d->S == 16 ? 2 : 4;
+    const unsigned wpb = d->S == 32 ? 1 : (d->S == 16 ? 2 : 4);
     const unsigned blocks = (unsigned)std::min<u64>((nreads + wpb - 1) / wpb, 256ull * 32);
     switch (d->S) {
         case 4: hipLaunchKernelGGL((k_probe<4, MODE, 4>), dim3(blocks), dim3(256), 0, d->stream, A); break;
         case 8: hipLaunchKernelGGL((k_probe<8, MODE, 4>), dim3(blocks), dim3(256), 0, d->stream, A); break;
         case 16: hipLaunchKernelGGL((k_probe<16, MODE, 2>), dim3(blocks), dim3(128), 0, d->stream, A); break;
+        case 32: hipLaunchKernelGGL((k_probe<32, MODE, 1>), dim3(blocks), dim3(64), 0, d->stream, A); break;     // 505 .. 1018 bases: 34 KB of LDS per wave
         default: err = "bad S"; return SAGE2OV_ERR_INTERNAL;
     }
     HIPCHK(hipGetLastError());

@@ -94,8 +94,8 @@ inline void stage_codes(sage2ov_ctx* c, const uint8_t* codes, int L, std::vector
                         uint64_t& good, uint64_t& bp, uint64_t& small) {
     if (L <= (int)c->cfg.min_overlap) { small++; return; }
     const int nw = (L + 31) / 32;
-    uint64_t f[18], r[18];
-    if (nw > 16) { lens.push_back(0xFFFF); off.push_back(pool.size()); good++; bp += L; return; }   // too long: organise reports the limit
+    uint64_t f[34], r[34];
+    if (nw > 32) { lens.push_back(0xFFFF); off.push_back(pool.size()); good++; bp += L; return; }   // too long: organise reports the limit
     for (int w = 0; w < nw; w++) f[w] = 0;
     for (int i = 0; i < L; i++) { if (codes[i] > 3) return; f[i >> 5] |= (uint64_t)codes[i] << (62 - 2 * (i & 31)); }
     // the forward strand is staged; the canonical orientation (readLoader.cpp:195) is chosen by the organiser (device or host)
@@ -105,7 +105,7 @@ inline void stage_codes(sage2ov_ctx* c, const uint8_t* codes, int L, std::vector
     good++; bp += L;
 }
 inline void canonicalise_words(uint64_t* f, int L) {        // readLoader.cpp:195: read < revcomp ? read : revcomp (tie: revcomp, same bytes)
-    const int nw = (L + 31) / 32; uint64_t r[18];
+    const int nw = (L + 31) / 32; uint64_t r[34];
     revcomp_words(f, nw, L, r);
     bool useF = false;
     for (int w = 0; w < nw; w++) { if (f[w] != r[w]) { useF = f[w] < r[w]; break; } }
@@ -582,8 +582,10 @@ static int upload(sage2ov_ctx* c) {
     return SAGE2OV_OK;
 }
 // a slot of S words holds the bases and, in the low 9 bits of its last word, the length: 123 / 251 / 507 bases for S = 4 / 8 / 16
-static constexpr uint64_t SLOT_LEN_MASK = 0x1FF;
-static int choose_S(int maxL) { int need = (2 * maxL + 9 + 63) / 64; int S = 4; while (S < need) S *= 2; return S; }
+static constexpr uint64_t slot_len_mask(int S) { return S > 16 ? 0x7FFull : 0x1FFull; }     // (kernels_common.inc: the 32-word layout keeps 11 bits)
+#define SLOT_LEN_MASK slot_len_mask(c->S)
+// words per slot: 2 bits per base + the length field (9 bits up to 16 words = 504 bases, 11 bits in the 32-word layout = 1018 bases)
+static int choose_S(int maxL) { int need = (2 * maxL + 9 + 63) / 64; int S = 4; while (S < need) S *= 2; if (S > 16) { need = (2 * maxL + 11 + 63) / 64; S = need <= 32 ? 32 : 64; } return S; }
 
 int sage2ov_reads_organize(sage2ov_ctx* c) {                                          // readLoader.cpp:215-260
     if (!c) return SAGE2OV_ERR_ARG;
@@ -611,9 +613,9 @@ int sage2ov_reads_organize(sage2ov_ctx* c) {                                    
     const uint64_t n = c->poolLen.size();
     int maxL = 0; for (uint64_t i = 0; i < n; i++) maxL = std::max<int>(maxL, c->poolLen[i]);
     c->maxL = maxL; c->S = choose_S(std::max(maxL, 1));
-    if (c->S > 16 || maxL > 504) return c->fail(SAGE2OV_ERR_LIMIT, "reads longer than 504 bases are not supported");
+    if (c->S > 32 || maxL > 1018) return c->fail(SAGE2OV_ERR_LIMIT, "reads longer than 1018 bases are not supported");
     if (n >= (1ull << 32)) return c->fail(SAGE2OV_ERR_LIMIT, "too many reads for the host organiser");
-    for (uint64_t i = 0; i < n; i++) if (c->poolLen[i] == 0xFFFF) return c->fail(SAGE2OV_ERR_LIMIT, "reads longer than 504 bases are not supported");
+    for (uint64_t i = 0; i < n; i++) if (c->poolLen[i] == 0xFFFF) return c->fail(SAGE2OV_ERR_LIMIT, "reads longer than 1018 bases are not supported");
     if (c->dev && !getenv("SAGE2OV_HOST_ORGANIZE")) {                                 // step 1 on the device: canonical orientation, sort, unique, ids
         uint64_t N = 0;
         int minL = n ? 0xFFFF : 0; for (uint64_t i = 0; i < n; i++) minL = std::min<int>(minL, c->poolLen[i]);
@@ -696,7 +698,7 @@ int sage2ov_reads_save(sage2ov_ctx* c, const char* path) {                      
     const int S = c->S;
     int rc = write_formatted(c, f, c->N, (size_t)(2 * c->maxL + 24), [&](uint64_t x, std::string& o) {
         const uint64_t i = x + 1; const int L = c->len[i]; const uint64_t* w = &c->words[i * S];
-        uint64_t tmp[18], r[18]; const int nw = (L + 31) / 32; for (int q = 0; q < nw; q++) tmp[q] = w[q]; if (nw == S) tmp[nw - 1] &= ~SLOT_LEN_MASK;
+        uint64_t tmp[34], r[34]; const int nw = (L + 31) / 32; for (int q = 0; q < nw; q++) tmp[q] = w[q]; if (nw == S) tmp[nw - 1] &= ~SLOT_LEN_MASK;
         revcomp_words(tmp, nw, L, r);
         char hd[48]; char* p = put_u(hd, c->freq[i]); *p++ = '\t'; p = put_u(p, (unsigned)L); *p++ = '\t';
         const size_t at = o.size(); o.resize(at + (size_t)(p - hd) + 2 * (size_t)L + 2);
@@ -716,7 +718,7 @@ int sage2ov_reads_load(sage2ov_ctx* c, const char* path) {                      
         seqs[i] = a.data(); maxL = std::max<int>(maxL, (int)ln[i]);
     }
     fclose(f);
-    c->maxL = maxL; c->S = choose_S(std::max(maxL, 1)); if (c->S > 16) return c->fail(SAGE2OV_ERR_LIMIT, "reads longer than 504 bases are not supported");
+    c->maxL = maxL; c->S = choose_S(std::max(maxL, 1)); if (c->S > 32) return c->fail(SAGE2OV_ERR_LIMIT, "reads longer than 1018 bases are not supported");
     c->N = N; const int S = c->S; c->words.assign((N + 1) * S, 0); c->len.assign(N + 1, 0); c->freq.assign(N + 1, 0);
     for (unsigned long long i = 1; i <= N; i++) {
         const int L = (int)ln[i]; uint64_t* w = &c->words[i * S];
@@ -737,7 +739,7 @@ int sage2ov_reads_export_words(const sage2ov_ctx* c, uint64_t* words, uint64_t c
 int sage2ov_reads_import_words(sage2ov_ctx* c, const uint64_t* words, uint64_t n_unique, uint32_t words_per_read, uint32_t max_read_length,
                                const uint16_t* frequency, uint64_t good_reads, uint64_t total_bp) {
     if (!c || !words) return SAGE2OV_ERR_ARG;
-    if (words_per_read != 4 && words_per_read != 8 && words_per_read != 16) return c->fail(SAGE2OV_ERR_ARG, "words_per_read must be 4, 8 or 16");
+    if (words_per_read != 4 && words_per_read != 8 && words_per_read != 16 && words_per_read != 32) return c->fail(SAGE2OV_ERR_ARG, "words_per_read must be 4, 8, 16 or 32");
     c->N = n_unique; c->S = (int)words_per_read; c->maxL = (int)max_read_length;
     c->words.assign(words, words + (n_unique + 1) * words_per_read);
     c->len.assign(n_unique + 1, 0); c->freq.assign(n_unique + 1, 0);
@@ -819,7 +821,7 @@ int sage2ov_hashtable_save(sage2ov_ctx* c, const char* path) {
     std::vector<Slot> slot(M + 1, Slot{0, 0, -1, -1, 0});                              // (index M is reachable: `while (p > M)`, hashTable.cpp:163)
     std::vector<uint64_t> entVal; std::vector<int64_t> entNext; entVal.reserve(4 * N); entNext.reserve(4 * N);
     for (uint64_t i = 1; i <= N; i++) {                                                // hashTable.cpp:94-109: serial, ids ascending, types 0..3
-        const int L = c->len[i], nw = (L + 31) / 32; uint64_t f[18], r[18];
+        const int L = c->len[i], nw = (L + 31) / 32; uint64_t f[34], r[34];
         for (int q = 0; q < nw; q++) f[q] = c->words[i * S + q];
         if (nw == S) f[nw - 1] &= ~SLOT_LEN_MASK;
         f[nw] = 0; revcomp_words(f, nw, L, r); r[nw] = 0;

@@ -9,12 +9,13 @@ namespace s2 {
 
 // ----------------------------------------------------------------------------------------------
 // HBM layout of the read store
-//   reads: (N+1) slots of S u64 words (S = 4, 8 or 16: a power of two so a read never straddles a
+//   reads: (N+1) slots of S u64 words (S = 4, 8, 16 or 32: a power of two so a read never straddles a
 //   64-byte sector boundary more than its size requires).  Base p of a read lives in word p/32 at
 //   bits 63-2(p%32)..62-2(p%32) (A0 C1 G2 T3): the byte-swapped image of the reference's MSB-first
 //   byte packing (utils.cpp:96), so unsigned word compare == the reference's byte compare.
 //   The read length sits in the low 9 bits of the slot's last word (SLOT_LEN_MASK 0x1FF; bases never reach
-//   there: S is chosen with 2*maxL + 9 <= 64*S).  Slot 0 is all zero (ids are 1-based).
+//   there: S is chosen with 2*maxL + 9 <= 64*S; the 32-word layout, 505..1018 bases, keeps 11 bits: slot_len_mask(S)).
+//   Slot 0 is all zero (ids are 1-based).
 // Index slot (8 bytes):  tag:24 | cnt:7 | payload:33
 //   0 = empty; cnt 1 -> payload is the single entry id*4+type; 2..99 -> payload = offset into csr[];
 //   127 -> long bucket (>= 100 entries, hashTable.cpp:111-123): never matches a lookup.

@@ -535,12 +535,13 @@ def test_key_width_boundaries_match_oracle(k):
     g.close(); o.close()
 
 
-@pytest.mark.parametrize("L", [120, 123, 124, 160, 161, 248, 250, 251, 252])
+@pytest.mark.parametrize("L", [120, 123, 124, 160, 161, 248, 250, 251, 252, 504, 505, 992, 993, 1018])
 def test_read_length_layout_boundaries_match_oracle(L):
     """Longest read exactly at / one past the limits of the read-store layouts: 123 (4 words per read: 247 bits of bases above the 9-bit
     length), 160 (8 words, 10-dword compares and the in-kernel state machine), 251 (8 words, 16-dword compares; bases and length share the
-    last dword), 252+ (16 words: sequential kernel).  Mixed lengths below it.  The packed reads are compared too."""
-    pd = dict(seed=70 + L, genome_len=40000, n_reads=12000, read_len=L, read_len_min=L - 40, err_ppm=1000)
+    last dword), 252-504 (16 words: sequential kernel), 505-1018 (32 words, 11-bit length field; 993+: bases and length share the last word).
+    Mixed lengths below it.  The packed reads are compared too."""
+    pd = dict(seed=70 + L, genome_len=40000, n_reads=12000 if L < 500 else 4000, read_len=L, read_len_min=L - 40, err_ppm=1000)
     bases, off = fx.make_reads(pd)
     m = dict(k=31)
     g, o = run_gpu(m, bases, off), run_oracle(m, bases, off)
@@ -807,3 +808,16 @@ def test_probe_kernel_choice_is_exact(pd, k, mode, monkeypatch):
     if mode == "sample":
         assert tm.probe_fast_launches >= 2 * tm.probe_kernel_launches            # a sample launch and the rest, per pass
     g.close(); o.close()
+
+
+@pytest.mark.gpu
+def test_reads_beyond_the_longest_layout_are_refused():
+    """1018 bases is the limit of the 32-word layout; a longer read is reported by the organiser (ASCII and device-pack path alike), not truncated."""
+    pd = dict(seed=5, genome_len=20000, n_reads=300, read_len=1019, read_len_min=900)
+    bases, off = fx.make_reads(pd)
+    ctx = s2.Context(31)
+    ctx.reads_add_ascii(bases, off)
+    with pytest.raises(Exception) as ei:
+        ctx.reads_organize()
+    assert "1018" in str(ei.value)
+    ctx.close()
