@@ -46,7 +46,7 @@ struct Device {
     hipStream_t stream = nullptr;
     hipEvent_t ev[8] = {};
     // reads
-    u64 N = 0; int S = 0, maxL = 0, k = 0, h = 0;
+    u64 N = 0; int S = 0, maxL = 0, k = 0, h = 0; double probeShare = 1.0;
     u64* reads = nullptr;        // (N+1)*S words, slot i = read id i
     // the same reads in LOCALITY order (slot p = the read at position p of the order by global minimiser): what the index entries point at and
     // what the probe kernels gather from -- a read's overlap partners are neighbours in the genome, hence (mostly) neighbours here
@@ -346,7 +346,13 @@ int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t
     WS(slots_ws, u64, WS_SLOTS, d->T); d->slots = slots_ws;
     WS(big, u64, WS_BIG, (u64)big_cap * 3);
     WS(csr_ws, u32, WS_CSR, std::max<u64>(1, 4 * N)); d->csr = csr_ws;
-    const bool wantMI = !getenv("SAGE2OV_NO_MINIMIZER_INDEX") && (d->h - std::min(d->h, 16) + 1) >= 8;
+    // The minimiser groups (second access path of the fast kernel) serve the reads that START a run of the locality order -- a quarter of the reads
+    // since window reuse -- and pay when the uniform table is far beyond the caches: 11 ms of probe time against 7.6 ms of build time at
+    // configs[2] on one GPU, nothing against 1.1 ms at configs[1], and 11 / world against 7.6 when the probe work is shared.  So they are
+    // built for big read sets probed (mostly) by this context; SAGE2OV_MINIMIZER_INDEX=0/1 overrides (tests force 1 on small inputs).
+    bool wantMI = (double)N * d->probeShare >= 24e6;
+    if (const char* ev = getenv("SAGE2OV_MINIMIZER_INDEX")) wantMI = atoi(ev) != 0;
+    if (getenv("SAGE2OV_NO_MINIMIZER_INDEX") || (d->h - std::min(d->h, 16) + 1) < 8) wantMI = false;
     u64 TL = 0; int tlBits = 0; u64 gW = 0;
     if (wantMI) { TL = IX_GW; tlBits = IX_GWLOG; while (TL < d->T / 4) { TL <<= 1; tlBits++; } gW = TL / IX_GW; }   // >= 2N group words
     const u64 nAlloc = std::max<u64>(4, (u64)n + 4);
@@ -514,6 +520,8 @@ static bool launch_fast_any(Device* d, ProbeArgs& A, unsigned blocks) {
     return true;
 }
 static unsigned fast_blocks(u64 n) { return (unsigned)std::min<u64>((n + FAST_CHUNK - 1) / FAST_CHUNK, 256ull * 16); }
+
+void dev_set_probe_share(Device* d, double share) { d->probeShare = share; }
 
 int dev_probe(Device* d, uint64_t lo, uint64_t hi, std::string& err) {
     HIPCHK(hipSetDevice(d->ordinal));

@@ -489,7 +489,7 @@ int sage2ov_ctx_create(const sage2ov_config* cfg, sage2ov_ctx** out) {
     if (!cfg || !out) { g_create_error = "null argument"; return SAGE2OV_ERR_ARG; }
     if (cfg->min_overlap == 0) { g_create_error = "min_overlap (-k) is required"; return SAGE2OV_ERR_ARG; }   // main.cpp:506-510
     std::string e; Device* d = nullptr;
-    if (cfg->device != SAGE2OV_DEVICE_NONE) { d = dev_create(cfg->device, e); if (!d) { g_create_error = e; return SAGE2OV_ERR_DEVICE; } }
+    if (cfg->device != SAGE2OV_DEVICE_NONE) { d = dev_create(cfg->device, e); if (!d) { g_create_error = e; return SAGE2OV_ERR_DEVICE; } dev_set_probe_share(d, 1.0 / (double)std::max<uint32_t>(1, cfg->world)); }
     auto* c = new sage2ov_ctx(); c->cfg = *cfg; c->dev = d;
     if (c->cfg.world == 0) c->cfg.world = 1;
     if (c->cfg.rank >= c->cfg.world) { g_create_error = "rank >= world"; if (d) dev_destroy(d); delete c; return SAGE2OV_ERR_ARG; }

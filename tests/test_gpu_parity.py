@@ -821,3 +821,21 @@ def test_reads_beyond_the_longest_layout_are_refused():
         ctx.reads_organize()
     assert "1018" in str(ei.value)
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pd,k", [
+    (dict(seed=91, genome_len=60000, n_reads=24000, read_len=150, err_ppm=0), 40),
+    (dict(seed=92, genome_len=60000, n_reads=24000, read_len=150, err_ppm=1500), 40),
+    (dict(seed=93, genome_len=40000, n_reads=16000, read_len=100, read_len_min=70, err_ppm=1000, n_repeat_families=3, repeat_copies=40, repeat_len=300), 21),
+    (dict(seed=94, genome_len=50000, n_reads=10000, read_len=250, err_ppm=800), 55),
+])
+def test_without_minimiser_groups_matches_oracle(pd, k, monkeypatch):
+    """what the library does by itself on small inputs (and on every rank of a multi-GPU run): no minimiser groups, every window that window reuse
+    leaves open probes the uniform table"""
+    monkeypatch.setenv("SAGE2OV_MINIMIZER_INDEX", "0")
+    bases, off = fx.make_reads(pd)
+    m = dict(k=k)
+    g, o = run_gpu(m, bases, off), run_oracle(m, bases, off)
+    assert_equals_oracle(g, o)
+    g.close(); o.close()
