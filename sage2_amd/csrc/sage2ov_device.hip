@@ -1300,7 +1300,10 @@ void dev_simplify_release(Device* d) { if (d->s4keep) { hipSetDevice(d->ordinal)
 
 int dev_simplify(Device* d, SimplifiedGraph& out, std::string& err) {
     HIPCHK(hipSetDevice(d->ordinal));
+    const bool timing = getenv("SAGE2OV_TIMING") != nullptr; auto tp = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) { if (!timing) return; auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[step 4] %-40s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(t - tp).count()); tp = t; };
     dev_simplify_release(d);
+    lap("release of the previous result");
     std::unique_ptr<S4Keep> keep(new S4Keep());
     S4Mem& mem = keep->mem; S4Graph& g = keep->g;
     const u64 N64 = d->N, np = d->n_final;
@@ -1323,6 +1326,7 @@ int dev_simplify(Device* d, SimplifiedGraph& out, std::string& err) {
     S4GET(tab, S4Pair, (size_t)1 << tabBits)
     u32 nh = (u32)(2 * np);
     hipStream_t st = d->stream;
+    lap("allocations");
     HIPCHK(hipEventRecord(d->ev[0], st));
     if (np) hipLaunchKernelGGL(k_s4_init, dim3(grid_for(np, 256)), dim3(256), 0, st, d->final_edges, (u64)np, g);
     auto rd = [&](u32* v, int n) -> int { return hipMemcpyAsync(v, dctr, n * sizeof(u32), hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess ? 0 : -1; };
@@ -1483,6 +1487,7 @@ int dev_simplify(Device* d, SimplifiedGraph& out, std::string& err) {
     }
     HIPCHK(hipEventRecord(d->ev[1], st)); HIPCHK(hipStreamSynchronize(st));
     float ms = 0; hipEventElapsedTime(&ms, d->ev[0], d->ev[1]);
+    lap("sweeps (host view)");
     S4GET(dstat, u64, 2)
     HIPCHK(hipMemsetAsync(dstat, 0, 2 * sizeof(u64), st));
     if (nh) hipLaunchKernelGGL(k_s4_stats, dim3(grid_for(nh / 2 + 1, 256)), b256, 0, st, g, nh, dstat);
@@ -1493,6 +1498,7 @@ int dev_simplify(Device* d, SimplifiedGraph& out, std::string& err) {
     for (void* p : {(void*)stA, (void*)stB, (void*)stC, (void*)spFlag, (void*)spPos, (void*)spList, (void*)tab, (void*)jobs, (void*)jobLen, (void*)jobStart, (void*)remA, (void*)remB, (void*)chain, (void*)g.adj, (void*)cursor, (void*)h0, (void*)h1,
                     (void*)isNew, (void*)newCnt, (void*)rank, (void*)cntScan, (void*)othA, (void*)othB}) mem.drop(p);
     g.adj = nullptr;
+    lap("statistics + release of the work buffers");
     keep->nh = nh; keep->listUsed = listUsed;
     d->s4keep = keep.release();
     return 0;
