@@ -40,7 +40,7 @@ typedef unsigned int u32;
 
 enum { WS_SLOTS, WS_CNT, WS_WHERE, WS_BIG, WS_CSR, WS_SLOW, WS_NEED, WS_DEG, WS_OFFS, WS_CURSOR, WS_KEYS, WS_KEEP, WS_POS, WS_OWNER, WS_FINAL,
        WS_PARTIAL, WS_IDS, WS_NEAR, WS_HITS, WS_MINH, WS_OCNT, WS_OOFF, WS_OCUR, WS_ORDER, WS_MI1, WS_MICNT, WS_MICUR, WS_KREC, WS_SLOTMH, WS_RA_DEG, WS_RA_OFF, WS_RA_CUR, WS_RA_ENT, WS_RA_RM, WS_ORG_POOL, WS_ORG_OFF, WS_ORG_LEN, WS_ORG_IMG, WS_ORG_K0, WS_ORG_K1, WS_ORG_V0, WS_ORG_V1, WS_ORG_HIST, WS_ORG_HSCAN, WS_ORG_FLAG, WS_ORG_UID, WS_ORG_HEAD, WS_RR_IN, WS_RR_DEGP, WS_RR_OFFP, WS_RR_ENTP, WS_RR_OUTP, WS_RR_WIDX, WS_RR_RANK, WS_RR_CUR, WS_RA_HEAVY, WS_RA_HSIZE, WS_RA_HSCR, WS_RR_LEN, WS_RR_COFF, WS_RR_OUTC,
-       WS_PT_K0, WS_PT_K1, WS_PT_P0, WS_PT_P1, WS_PT_M0, WS_PT_M1, WS_PT_CNT, WS_PT_BASE, WS_PT_OFF, WS_PT_GOFF, WS_RR_LOC, WS_RR_RANKL, WS_LOC_READS, WS_LOC_IDOF, WS_LOC_POSOF, WS_LOC_STATUS, WS_ORG_GFLAG, WS_ORG_GPOS, WS_LOC_META, WS_SLOW2, WS_RA_ENT32, WS_RA_SPLIT, WS_COUNT };   // ids of the workspace arena (Device::ws)
+       WS_PT_K0, WS_PT_K1, WS_PT_P0, WS_PT_P1, WS_PT_M0, WS_PT_M1, WS_PT_CNT, WS_PT_BASE, WS_PT_OFF, WS_PT_GOFF, WS_RR_LOC, WS_RR_RANKL, WS_LOC_READS, WS_LOC_IDOF, WS_LOC_POSOF, WS_LOC_STATUS, WS_ORG_GFLAG, WS_ORG_GPOS, WS_LOC_META, WS_SLOW2, WS_RA_ENT32, WS_RA_SPLIT, WS_PRE_BASE, WS_PRE_NONE, WS_COUNT };   // ids of the workspace arena (Device::ws)
 struct Device {
     int ordinal = 0;
     hipStream_t stream = nullptr;
@@ -64,6 +64,8 @@ struct Device {
     // final edges (device resident)
     FinalEdge* final_edges = nullptr; u64 n_final = 0;
     DevTimings tm;
+    // hits written out by the initial pass (k_probe_fast<..., TAIL = 2> on noisy data, one context probing everything): the reduce phase filters them
+    struct PreHits { bool valid = false; Hit* hits = nullptr; u64 cap = 0, used = 0; u64* base = nullptr; } pre;
     void* s4keep = nullptr;      // step 4: the simplified graph stays in HBM until the next call (S4Keep)
     // workspace arena: buffers of the timed path are allocated once and only ever grow (no hipMalloc/hipFree per step)
     struct Buf { void* p = nullptr; size_t cap = 0; };
@@ -508,11 +510,11 @@ static void launch_fast(Device* d, ProbeArgs& A, unsigned blocks) { hipLaunchKer
 // picks the instantiation for the resident reads; false: the 16-word layout has no fast kernel
 template <int HITS, int TAIL>
 static bool launch_fast_any(Device* d, ProbeArgs& A, unsigned blocks) {
-    constexpr int FW = SAGE2OV_FAST_WPB;      // waves per block: a whole CU's worth works on one locality chunk
+    constexpr int FW = HITS ? 4 : SAGE2OV_FAST_WPB;      // waves per block: a whole CU's worth works on one locality chunk (hit-list form: 142 VGPRs = three waves per SIMD, which only blocks of four waves can fill)
     const int nwinMax = d->maxL - d->h + 1;                               // windows of the longest read
     if (d->S == 4 && nwinMax <= 128) launch_fast<4, 8, 2, FW, HITS, TAIL>(d, A, blocks);
     else if (d->S == 8 && d->maxL <= 160 && nwinMax <= 128) launch_fast<8, 10, 2, FW, HITS, TAIL>(d, A, blocks);
-    else if (d->S == 8 && d->maxL <= 160) launch_fast<8, 10, 3, FW, HITS, TAIL>(d, A, blocks);      // 129..160 windows, e.g. 150-bp reads with k <= 22
+    else if (d->S == 8 && d->maxL <= 160) launch_fast<8, 10, 3, 4, HITS, TAIL>(d, A, blocks);       // 129..160 windows, e.g. 150-bp reads with k <= 22 (three waves per SIMD: blocks of four)
     // (the 16-dword layout's state-machine rows take 12 KB of LDS per wave: four waves per block keep three blocks on a CU)
     else if (d->S == 8 && nwinMax <= 128) launch_fast<8, 16, 2, ((HITS || !TAIL) ? FW : 4), HITS, TAIL>(d, A, blocks);
     else if (d->S == 8) launch_fast<8, 16, 4, ((HITS || !TAIL) ? FW : 4), HITS, TAIL>(d, A, blocks);
@@ -533,6 +535,7 @@ int dev_probe(Device* d, uint64_t lo, uint64_t hi, std::string& err) {
     HIPCHK(hipMemsetAsync(d->d_counters + 6, 0, sizeof(u64), d->stream));
     ProbeArgs A = base_args(d); A.lo = lo; A.hi = hi;
     const u64 nreads = hi > lo ? hi - lo : 0;
+    d->pre.valid = false;
     const bool seq_only = getenv("SAGE2OV_SEQUENTIAL_PROBE") != nullptr;
     if (nreads && !seq_only) {
         WS(slow, u32, WS_SLOW, nreads);
@@ -566,6 +569,24 @@ int dev_probe(Device* d, uint64_t lo, uint64_t hi, std::string& err) {
             if (getenv("SAGE2OV_TIMING")) fprintf(stderr, "[probe] fast kernel launch %.3f ms, listed so far %llu\n", ms, (unsigned long long)nslow);
             return 0;
         };
+        // noisy data, and this context probes every read: the hits of the unresolved reads ARE the verified hits of this pass -- written out
+        // now (k_probe_fast<..., 2> with hitBase), filtered by the final statuses in the reduce phase (k_hits_filter)
+        auto arm_prehits = [&](ProbeArgs& P, u64 nr, unsigned nb, bool& armed) -> int {
+            armed = false;
+            if (!(tailKernel == 2 && d->probeShare == 1.0 && lo == 1 && hi == N + 1 && !getenv("SAGE2OV_NO_PREHITS"))) return 0;
+            const u64 hcap = nr * 72 + (u64)nb * SAGE2OV_FAST_WPB * HITS_CHUNK;
+            WS(hb, Hit, WS_HITS, hcap); WS(hbase, u64, WS_PRE_BASE, N + 2); WS(hcnt, u32, WS_RA_CUR, N + 2);
+            HIPCHK(hipMemsetAsync(hbase, 0xFF, (N + 2) * sizeof(u64), d->stream)); HIPCHK(hipMemsetAsync(hcnt, 0, (N + 2) * sizeof(u32), d->stream));
+            HIPCHK(hipMemsetAsync(d->d_counters + 4, 0, 2 * sizeof(u64), d->stream));
+            P.hits = hb; P.hits_cap = hcap; P.hitBase = hbase; P.hitcount = hcnt; armed = true;
+            d->pre.hits = hb; d->pre.cap = hcap; d->pre.base = hbase;
+            return 0;
+        };
+        auto close_prehits = [&]() -> int {
+            u64 used = 0; HIPCHK(hipMemcpyAsync(&used, d->d_counters + 4, sizeof used, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
+            d->pre.used = used; d->pre.valid = used <= d->pre.cap;                   // (a chunk beyond the buffer: hits were dropped, the reduce phase makes its own lists)
+            return 0;
+        };
         if (nsample && nsample < nreads) {
             ProbeArgs As = A; As.hi = lo + nsample;
             int rc = timed([&] { launched = launch_fast_any<0, 0>(d, As, fast_blocks(nsample)); }); if (rc) return rc;
@@ -573,11 +594,15 @@ int dev_probe(Device* d, uint64_t lo, uint64_t hi, std::string& err) {
                 anyListed = true;
                 tailKernel = nslow * 2 > nsample ? 2 : (nslow * 32 > nsample ? 1 : 0);   // listed: more than half -> state machine for every read; more than 3 % -> kernel that carries it
                 ProbeArgs Ar = A; Ar.lo = lo + nsample; const unsigned nb = fast_blocks(nreads - nsample);
+                bool armed = false; { int rca = arm_prehits(Ar, nreads - nsample, nb, armed); if (rca) return rca; }
                 rc = timed([&] { if (tailKernel == 2) launch_fast_any<0, 2>(d, Ar, nb); else if (tailKernel == 1) launch_fast_any<0, 1>(d, Ar, nb); else launch_fast_any<0, 0>(d, Ar, nb); }); if (rc) return rc;
+                if (armed) { int rca = close_prehits(); if (rca) return rca; }
             }
         } else {
             const unsigned nb = fast_blocks(nreads);
-            int rc = timed([&] { launched = tailKernel == 2 ? launch_fast_any<0, 2>(d, A, nb) : (tailKernel == 1 ? launch_fast_any<0, 1>(d, A, nb) : launch_fast_any<0, 0>(d, A, nb)); }); if (rc) return rc;
+            ProbeArgs Aw = A; bool armed = false; { int rca = arm_prehits(Aw, nreads, nb, armed); if (rca) return rca; }
+            int rc = timed([&] { launched = tailKernel == 2 ? launch_fast_any<0, 2>(d, Aw, nb) : (tailKernel == 1 ? launch_fast_any<0, 1>(d, Aw, nb) : launch_fast_any<0, 0>(d, Aw, nb)); }); if (rc) return rc;
+            if (armed && launched) { int rca = close_prehits(); if (rca) return rca; }
         }
         if (!launched) {                                                       // 16-word layout: sequential kernel only (for now)
             HIPCHK(hipEventRecord(d->ev[2], d->stream));
@@ -948,7 +973,7 @@ int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved
     auto lap = [&](const char* what) { if (!timing) return; hipStreamSynchronize(d->stream); auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[reduce/device] %-30s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(t - tp).count()); tp = t; };
     // directional hits of the unresolved reads, device resident: the fast kernel in its hit-list form (locality order, minimiser
     // groups), the sequential kernel for the few reads it hands over (> 128 candidates, ambiguous tags) and for the 16-word layout
-    Hit* dh = nullptr; u64 nh = 0, nslots = 0;
+    Hit* dh = nullptr; u64 nh = 0, nslots = 0; u64 dbgFastEnd = 0;
     WS(hitcount, u32, WS_RA_CUR, N + 2);
     u32* locDev = nullptr;                                                       // ranked form: read id -> 1-based position in the locality order
     {
@@ -968,6 +993,34 @@ int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved
         const unsigned blocks = (unsigned)std::min<u64>((N + FAST_CHUNK - 1) / FAST_CHUNK, 256ull * 16);
         u64 cap = std::max<u64>(1 << 16, nun * 80) + (u64)blocks * SAGE2OV_FAST_WPB * HITS_CHUNK; bool ok = false;
         if (getenv("SAGE2OV_TEST_SMALL_BUFFERS")) cap = 8192;                      // tests: start far too small, the sizing loop must recover
+        // The initial pass may have written every read's hits out already (dev_probe, noisy data): drop the ones with a resolved end, in place, and
+        // run the hit-list kernel only for the unresolved reads that pass did not cover (its sample, hand-overs).  Any shortage of room: the
+        // ordinary way below, from scratch.
+        if (d->pre.valid && !getenv("SAGE2OV_TEST_SMALL_BUFFERS")) {
+            d->pre.valid = false;                                                     // (consumed: the filter works in place)
+            dh = d->pre.hits; const u64 pcap = d->pre.cap; u64 used = d->pre.used;
+            WS(noneList, u32, WS_PRE_NONE, N + 2);
+            HIPCHK(hipMemsetAsync(d->d_counters + 22, 0, 2 * sizeof(u64), d->stream));
+            hipLaunchKernelGGL(k_hits_filter, dim3((unsigned)std::min<u64>((N + 3) / 4, 256ull * 64)), dim3(256), 0, d->stream, dh, d->pre.base, d->status, d->posOf, (u64)N, hitcount, noneList, d->d_counters + 22);
+            u64 fc[2] = {0, 0}; HIPCHK(hipMemcpyAsync(fc, d->d_counters + 22, sizeof fc, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
+            HIPCHK(hipGetLastError());
+            nh = fc[0]; ok = true;
+            if (fc[1]) {                                                              // unresolved reads without written hits: the hit-list kernel over their positions, appending
+                u64 c3[3] = {used, 0, 0}; HIPCHK(hipMemcpyAsync(d->d_counters + 4, c3, sizeof c3, hipMemcpyHostToDevice, d->stream));
+                ProbeArgs A = base_args(d); A.ids = noneList; A.n_ids = fc[1]; A.hits = dh; A.hits_cap = pcap; A.hitcount = hitcount; A.slow = slow; A.slow_cap = N + 1;
+                if (launch_fast_any<1, 0>(d, A, fast_blocks(fc[1]))) {
+                    HIPCHK(hipGetLastError());
+                    HIPCHK(hipMemcpyAsync(c3, d->d_counters + 4, sizeof c3, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
+                    if (c3[0] > pcap) ok = false;
+                    else if (c3[2]) { ProbeArgs B = base_args(d); B.hits = dh; B.hits_cap = pcap; B.hitcount = hitcount; B.ids = slow; B.n_ids = c3[2]; int rc = launch_probe<1>(d, B, err); if (rc) return rc; }
+                } else { A.slow = nullptr; int rc = launch_probe<1>(d, A, err); if (rc) return rc; }
+                if (ok) {
+                    u64 used2 = 0; HIPCHK(hipMemcpyAsync(&used2, d->d_counters + 4, sizeof used2, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
+                    if (used2 > pcap) ok = false; else { nh += c3[1] + (used2 - std::max(c3[0], used)); used = used2; }
+                }
+            }
+            if (ok) nslots = used;
+        }
         for (int attempt = 0; attempt < 4 && !ok; attempt++) {
             WS(hb, Hit, WS_HITS, cap); dh = hb;
             HIPCHK(hipMemsetAsync(d->d_counters + 4, 0, 3 * sizeof(u64), d->stream));
@@ -979,6 +1032,7 @@ int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved
                 HIPCHK(hipGetLastError());
                 HIPCHK(hipMemcpyAsync(c3, d->d_counters + 4, sizeof c3, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
                 if (c3[0] > cap) { cap = c3[0] + c3[0] / 8 + 1024; continue; }            // some chunk did not fit: everything again
+                dbgFastEnd = c3[0];
                 if (c3[2]) {                                                                  // handed over: exact sequential kernel, appends behind
                     ProbeArgs B = base_args(d); B.hits = dh; B.hits_cap = cap; B.hitcount = hitcount; B.ids = slow; B.n_ids = c3[2];
                     int rc = launch_probe<1>(d, B, err); if (rc) return rc;
@@ -996,6 +1050,13 @@ int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved
     }
     *n_hits = nh;
     lap("hit lists");
+    if (getenv("SAGE2OV_DEBUG_HITS") && nslots) {                                    // diagnostic: an order-independent checksum of the hit lists
+        std::vector<Hit> hh(nslots); HIPCHK(hipMemcpy(hh.data(), dh, nslots * sizeof(Hit), hipMemcpyDeviceToHost));
+        u64 sum = 0, cnt = 0, sumseq = 0, sumF = 0, cntF = 0; u64 idx = 0;
+        for (const Hit& h : hh) { const bool fastPart = idx++ < dbgFastEnd; if (h.from) { u64 x = ((u64)h.from << 32) ^ ((u64)h.to * 0x9E3779B97F4A7C15ull) ^ ((u64)(u32)h.len << 8) ^ h.type; x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; sum += x; sumseq += h.seq; cnt++; if (fastPart) { sumF += x; cntF++; } } }
+        if (const char* path = getenv("SAGE2OV_DEBUG_HITS_FILE")) { FILE* f = fopen(path, "wb"); if (f) { fwrite(hh.data(), sizeof(Hit), (size_t)std::min<u64>(dbgFastEnd, nslots), f); fclose(f); } }
+        fprintf(stderr, "[reduce/device] hits %llu in %llu slots, checksum %016llx, seq sum %llu, nh %llu; fast kernel's part: %llu hits, checksum %016llx\n", (unsigned long long)cnt, (unsigned long long)nslots, (unsigned long long)sum, (unsigned long long)sumseq, (unsigned long long)nh, (unsigned long long)cntF, (unsigned long long)sumF);
+    }
     const u64 nc = d->n_cand;
     WS(deg, u32, WS_RA_DEG, N + 2); WS(offs, u32, WS_RA_OFF, N + 2); WS(cur, u32, WS_CURSOR, N + 2);
     HIPCHK(hipMemsetAsync(deg, 0, (N + 2) * sizeof(u32), d->stream)); HIPCHK(hipMemsetAsync(cur, 0, (N + 2) * sizeof(u32), d->stream));

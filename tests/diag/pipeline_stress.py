@@ -24,6 +24,12 @@ for seed in range(n0, n1):
     ok = np.array_equal(gc, orc) and np.array_equal(gr[1:], orr[1:]) and np.array_equal(gl[1:], orl[1:]) and len(e) == len(oe) and np.array_equal(e["from"], oe[:, 0]) \
         and np.array_equal(e["to"], oe[:, 1]) and np.array_equal(e["type"], oe[:, 2]) and np.array_equal(e["length"], oe[:, 3]) and np.array_equal(e["length_twin"], oe[:, 4]) \
         and (st.edges_inserted, st.transitive_removed, st.verified_overlaps) == (o.counter("edges_inserted"), o.counter("transitive_removed"), o.counter("n_ov"))
-    if not ok: bad += 1; print("MISMATCH seed", seed, pd, "k", k, flush=True)
+    if not ok:
+        bad += 1; print("MISMATCH seed", seed, pd, "k", k, flush=True)
+        print("   conn", np.array_equal(gc, orc), "right", np.array_equal(gr[1:], orr[1:]), "left", np.array_equal(gl[1:], orl[1:]), "edges", len(e), len(oe),
+              "counters", (st.edges_inserted, st.transitive_removed, st.verified_overlaps), (o.counter("edges_inserted"), o.counter("transitive_removed"), o.counter("n_ov")),
+              "records differing", int((gr[1:] != orr[1:]).sum()), int((gl[1:] != orl[1:]).sum()), int((gc != orc).sum()),
+              "initial classes differing", int((np.where(np.isin(gs[1:], (1, 2)), 0, gs[1:]) != np.where(np.isin(ors[1:], (1, 2)), 0, ors[1:])).sum()),
+              "unresolved", st.left_to_explore, int((ors[1:] == 0).sum() + np.isin(ors[1:], (1, 2)).sum()), flush=True)
     g.close(); o.close()
 print("data sets", n1 - n0, "mismatches", bad, flush=True)
