@@ -510,7 +510,7 @@ static void launch_fast(Device* d, ProbeArgs& A, unsigned blocks) { hipLaunchKer
 // picks the instantiation for the resident reads; false: the 16-word layout has no fast kernel
 template <int HITS, int TAIL>
 static bool launch_fast_any(Device* d, ProbeArgs& A, unsigned blocks) {
-    constexpr int FW = HITS ? 4 : SAGE2OV_FAST_WPB;      // waves per block: a whole CU's worth works on one locality chunk (hit-list form: 142 VGPRs = three waves per SIMD, which only blocks of four waves can fill)
+    constexpr int FW = SAGE2OV_FAST_WPB;      // waves per block: a whole CU's worth works on one locality chunk
     const int nwinMax = d->maxL - d->h + 1;                               // windows of the longest read
     if (d->S == 4 && nwinMax <= 128) launch_fast<4, 8, 2, FW, HITS, TAIL>(d, A, blocks);
     else if (d->S == 8 && d->maxL <= 160 && nwinMax <= 128) launch_fast<8, 10, 2, FW, HITS, TAIL>(d, A, blocks);
