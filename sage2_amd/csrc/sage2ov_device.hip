@@ -575,7 +575,9 @@ int dev_probe(Device* d, uint64_t lo, uint64_t hi, std::string& err) {
             armed = false;
             if (!(tailKernel == 2 && d->probeShare == 1.0 && lo == 1 && hi == N + 1 && !getenv("SAGE2OV_NO_PREHITS"))) return 0;
             const u64 hcap = nr * 72 + (u64)nb * SAGE2OV_FAST_WPB * HITS_CHUNK;
-            WS(hb, Hit, WS_HITS, hcap); WS(hbase, u64, WS_PRE_BASE, N + 2); WS(hcnt, u32, WS_RA_CUR, N + 2);
+            Hit* hb = (Hit*)ws_get(d, WS_HITS, hcap * sizeof(Hit));                  // (72 hits per read: 49 GB at 42 M reads -- no room: the reduce phase makes its own lists)
+            if (!hb) { (void)hipGetLastError(); return 0; }
+            WS(hbase, u64, WS_PRE_BASE, N + 2); WS(hcnt, u32, WS_RA_CUR, N + 2);
             HIPCHK(hipMemsetAsync(hbase, 0xFF, (N + 2) * sizeof(u64), d->stream)); HIPCHK(hipMemsetAsync(hcnt, 0, (N + 2) * sizeof(u32), d->stream));
             HIPCHK(hipMemsetAsync(d->d_counters + 4, 0, 2 * sizeof(u64), d->stream));
             P.hits = hb; P.hits_cap = hcap; P.hitBase = hbase; P.hitcount = hcnt; armed = true;
