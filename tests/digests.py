@@ -28,6 +28,8 @@ CONFIGS = {
     "c2": dict(k=40, synth=dict(seed=2, genome_len=30_000_000, n_reads=10_000_000, read_len=150)),
     "c2_noisy": dict(k=40, synth=dict(seed=2, genome_len=30_000_000, n_reads=10_000_000, read_len=150, err_ppm=1000)),
     "c3": dict(k=40, synth=dict(seed=3, genome_len=150_000_000, n_reads=50_000_000, read_len=150)),
+    # read errors AND high-copy repeats: long buckets, one-sided discovery, the reduce phase's result depends on the exploration order
+    "c2_repeat": dict(k=40, synth=dict(seed=2, genome_len=30_000_000, n_reads=10_000_000, read_len=150, err_ppm=1000, n_repeat_families=10, repeat_copies=300, repeat_len=400)),
     # small ones: the digest machinery itself is tested on these (CPU test: oracle vs committed digest; GPU test: device vs digest)
     "c1": dict(k=21, synth=dict(seed=1, genome_len=200_000, n_reads=100_000, read_len=100)),
     "c2_1m": dict(k=40, synth=dict(seed=2, genome_len=3_000_000, n_reads=1_000_000, read_len=150)),

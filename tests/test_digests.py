@@ -39,7 +39,7 @@ def test_digest_lookup_by_parameters():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["c1", "c2_1m", "c2", "c2_noisy", "c3"])
+@pytest.mark.parametrize("name", ["c1", "c2_1m", "c2", "c2_noisy", "c2_repeat", "c3"])
 def test_gpu_reproduces_full_size_digest(name, tmp_path):
     """BASELINE sizes the oracle cannot run inside a test: every number the restatement produced for this input (make_digests.py) must
     come out of the device path -- n_unique, N_ov (the numerator of the headline metric), crc32 of connections / extension records /
