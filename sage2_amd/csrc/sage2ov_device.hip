@@ -1003,7 +1003,7 @@ int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved
             dh = d->pre.hits; const u64 pcap = d->pre.cap; u64 used = d->pre.used;
             WS(noneList, u32, WS_PRE_NONE, N + 2);
             HIPCHK(hipMemsetAsync(d->d_counters + 22, 0, 2 * sizeof(u64), d->stream));
-            hipLaunchKernelGGL(k_hits_filter, dim3((unsigned)std::min<u64>((N + 3) / 4, 256ull * 64)), dim3(256), 0, d->stream, dh, d->pre.base, d->status, d->posOf, (u64)N, hitcount, noneList, d->d_counters + 22);
+            hipLaunchKernelGGL(k_hits_filter, dim3((unsigned)std::min<u64>((N + 3) / 4, 256ull * 64)), dim3(256), 0, d->stream, dh, d->pre.base, d->status, d->statusP, d->idOf, d->posOf, (u64)N, hitcount, noneList, d->d_counters + 22);
             u64 fc[2] = {0, 0}; HIPCHK(hipMemcpyAsync(fc, d->d_counters + 22, sizeof fc, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
             HIPCHK(hipGetLastError());
             nh = fc[0]; ok = true;
