@@ -783,7 +783,7 @@ def test_table_beyond_2_to_32_slots(monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["sample", "tail0", "tail1", "tail2"])
+@pytest.mark.parametrize("mode", ["sample", "tail0", "tail1", "tail2", "tail2_own_hit_lists"])
 @pytest.mark.parametrize("pd,k", [
     (dict(seed=71, genome_len=60000, n_reads=20000, read_len=150, err_ppm=0), 40),                          # clean: the sample keeps the kernel without the state machine
     (dict(seed=72, genome_len=60000, n_reads=20000, read_len=150, err_ppm=1500), 40),                       # noisy: the sample switches to the kernel with it
@@ -799,7 +799,9 @@ def test_probe_kernel_choice_is_exact(pd, k, mode, monkeypatch):
     if mode == "sample":
         monkeypatch.setenv("SAGE2OV_PROBE_SAMPLE_MIN", "2048")
     else:
-        monkeypatch.setenv("SAGE2OV_PROBE_TAIL", mode[-1])
+        monkeypatch.setenv("SAGE2OV_PROBE_TAIL", "2" if mode.startswith("tail2") else mode[-1])
+        if mode == "tail2_own_hit_lists":                                            # TAIL = 2 writes its hits out for the reduce phase: here the reduce phase makes its own
+            monkeypatch.setenv("SAGE2OV_NO_PREHITS", "1")
     bases, off = fx.make_reads(pd)
     m = dict(k=k)
     g, o = run_gpu(m, bases, off), run_oracle(m, bases, off)
@@ -834,6 +836,25 @@ def test_without_minimiser_groups_matches_oracle(pd, k, monkeypatch):
     """what the library does by itself on small inputs (and on every rank of a multi-GPU run): no minimiser groups, every window that window reuse
     leaves open probes the uniform table"""
     monkeypatch.setenv("SAGE2OV_MINIMIZER_INDEX", "0")
+    bases, off = fx.make_reads(pd)
+    m = dict(k=k)
+    g, o = run_gpu(m, bases, off), run_oracle(m, bases, off)
+    assert_equals_oracle(g, o)
+    g.close(); o.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pd,k", [
+    (dict(seed=16388, genome_len=73072, n_reads=28823, read_len=161, read_len_min=150, err_ppm=1500, n_repeat_families=1, repeat_copies=233, repeat_len=136), 40),
+    (dict(seed=16461, genome_len=29064, n_reads=26966, read_len=161, err_ppm=1500, n_repeat_families=2, repeat_copies=161, repeat_len=348), 70),
+    (dict(seed=301, genome_len=60000, n_reads=24000, read_len=200, err_ppm=1500, n_repeat_families=3, repeat_copies=150, repeat_len=300), 31),
+    (dict(seed=302, genome_len=50000, n_reads=20000, read_len=250, read_len_min=170, err_ppm=3000, n_repeat_families=2, repeat_copies=250, repeat_len=200), 55),
+])
+def test_mid_length_reads_in_repeats_match_oracle(pd, k, monkeypatch):
+    """161-251-bp reads (16-dword instantiations of the fast kernel) with read errors and high-copy repeats, device reduce forced: the hit-list
+    kernel of these layouts returned wrong overhang lengths when it was compiled with spilled registers (the first two data
+    sets are the ones the stress generator found it with)."""
+    monkeypatch.setenv("SAGE2OV_DEVICE_REDUCE_MIN", "1")
     bases, off = fx.make_reads(pd)
     m = dict(k=k)
     g, o = run_gpu(m, bases, off), run_oracle(m, bases, off)
