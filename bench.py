@@ -145,6 +145,33 @@ def cpu_baseline_subprocess(args):
     return None
 
 
+def spawn_ranks(n):
+    """One child process per rank (fresh interpreters; the parent initialises no GPU runtime, so nothing is ever exec'ed over a live HIP
+    context), rendezvous on 127.0.0.1.  Returns the first non-zero exit code; a rank that fails takes the others down with it."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]
+    base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    out = procs[0].stdout.read().decode()
+    for r, pr in enumerate(procs):
+        c = pr.wait()
+        if c and not rc:
+            rc = c
+            log(f"[bench] rank {r} exited with code {c}")
+            for q in procs:                                  # the exact children started above, nothing else
+                if q.poll() is None:
+                    q.terminate()
+    sys.stdout.write(out); sys.stdout.flush()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -175,6 +202,10 @@ def main():
         import sage2_amd as s2
         print(json.dumps(cpu_baseline(args, s2, fx)), flush=True)
         return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: this process becomes the launcher (it never touches HIP or torch.cuda) and starts
+        # one child per GPU with the torchrun environment; rank 0's JSON line is relayed, every child's stderr passes through
+        sys.exit(spawn_ranks(args.gpus))
 
     import numpy as np
     import torch
@@ -185,8 +216,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    # SAGE2OV_BENCH_FORCE_SHARDED=1: one rank, but through the multi-rank code path (process group, record / flag / edge collectives on RCCL):
+    # what `torchrun --nproc-per-node 1` rehearses on a one-GPU box before the first real multi-GPU run
+    sharded = world > 1 or os.environ.get("SAGE2OV_BENCH_FORCE_SHARDED", "0") not in ("", "0")
+    if sharded:
         import torch.distributed as dist
+        for kk, vv in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29577"), ("RANK", "0"), ("WORLD_SIZE", "1")):
+            os.environ.setdefault(kk, vv)                           # (forced one-rank run without a launcher)
         backend = os.environ.get("SAGE2OV_BENCH_BACKEND", "nccl")      # "gloo": rehearsal of the N>1 path on a box with fewer GPUs than ranks
         if backend != "nccl":
             local = local % torch.cuda.device_count()
@@ -195,6 +231,7 @@ def main():
             torch.cuda.set_device(local)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     assert torch.cuda.is_available(), "bench.py needs a GPU: the hot path has no CPU fallback"
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}, or without a launcher (bench.py then starts its own ranks)"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
@@ -209,7 +246,7 @@ def main():
         st = ctx.reads_stats()
         log(f"[bench] rank 0: {st.good_reads} good reads -> {st.unique_reads} unique, generated + organised in {time.time() - t0:.1f} s "
             f"(step 1 on the device: {ctx.timings().organize_ms:.1f} ms)")
-    if world > 1:
+    if sharded:
         # rank 0 organised the reads; everybody else imports the HBM image (broadcast over RCCL)
         meta = torch.zeros(6, dtype=torch.int64, device=dev)
         if rank == 0:
@@ -231,14 +268,14 @@ def main():
     st = ctx.reads_stats()
 
     def step():
-        if world > 1:
+        if sharded:
             from sage2_amd.dist import run_steps23_sharded
             run_steps23_sharded(ctx, dev)
         else:
             ctx.run_steps23()
 
     def fence():
-        if world > 1:
+        if sharded:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -258,7 +295,7 @@ def main():
         pk_f += tm.probe_fast_launches
     fence()
     elapsed = time.perf_counter() - t1
-    if world > 1:
+    if sharded:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -269,17 +306,19 @@ def main():
     del ed
     # the oracle's numbers for this exact input (tests/golden/*_digest.json, oracle/make_digests.py): N, N_ov, edge count and edge-list crc32
     dname, want = dg.lookup(args.k, pd)
-    digest_checked = None
+    digest_checked, bad = None, []
     if want is not None:
         got = dict(n_unique=st.unique_reads, n_ov=ost.verified_overlaps, edges=ost.edges, edges_crc32=edges_crc)
         bad = dg.compare(got, want, keys=list(got))
-        assert not bad, f"result differs from the oracle digest {dname}: " + "; ".join(bad)
         digest_checked = dname
-    if world > 1:
-        t = torch.tensor([edges_crc], dtype=torch.int64, device=dev)
-        tmin, tmax = t.clone(), t.clone()
-        dist.all_reduce(tmin, op=dist.ReduceOp.MIN); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        assert int(tmin.item()) == int(tmax.item()) == edges_crc, "ranks disagree on the final edge list"
+    if sharded:
+        # every rank takes part in the collectives BEFORE anybody asserts: a mismatch on one rank must fail the run, not hang the others
+        t = torch.tensor([edges_crc, -edges_crc, 0 if bad else 1], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        cmin, cmax, all_ok = int(t[0].item()), -int(t[1].item()), int(t[2].item())
+        assert cmin == cmax == edges_crc, "ranks disagree on the final edge list"
+        assert all_ok == 1 or bad, f"another rank's result differs from the oracle digest {dname}"
+    assert not bad, f"result differs from the oracle digest {dname}: " + "; ".join(bad)
     ms_per_step = 1e3 * elapsed / args.steps
     value = ost.verified_overlaps / (elapsed / args.steps)
 
@@ -298,19 +337,27 @@ def main():
         if os.path.exists(tj) and args.err_ppm == 0 and world == 1:
             try:
                 te = json.load(open(tj)).get(f"{args.reads}x{args.read_len}_k{args.k}_seed{args.seed}", {})
-                traffic, traffic_src = te.get("bytes_per_launch"), te.get("source")
+                import hashlib
+                sha = hashlib.sha1(b"".join(open(os.path.join(ROOT, "sage2_amd", "csrc", nm), "rb").read() for nm in ("kernels_probe_fast.inc", "kernels_common.inc"))).hexdigest()
+                if te.get("kernel_source_sha1") == sha:              # a PMC pass of THIS kernel source; anything older is stale: null
+                    traffic, traffic_src = te.get("bytes_per_launch"), te.get("source")
             except Exception:
                 traffic = None
         res = {
             "metric": "overlaps/sec + edge-set bit-identity vs OpenMP ref, 150 bp reads k=40",
-            "value": value, "unit": "overlaps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": "overlaps/s", "n_gpus": world, "world_size": (dist.get_world_size() if dist is not None else 1),
+            "collectives": (dist.get_backend() if dist is not None else None), "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"{args.reads} x {args.read_len} bp synthetic paired-end reads, k={args.k}, {args.genome} bp uniform random genome, "
                                    f"seed {args.seed}, err {args.err_ppm} ppm ({cfg_name})",
                        "unique_reads": st.unique_reads, "verified_overlaps": ost.verified_overlaps, "edges": ost.edges, "edges_crc32": edges_crc,
-                       "unresolved_reads": ost.left_to_explore, "partition": f"read-id range x{world}" if world > 1 else "single GPU",
+                       "unresolved_reads": ost.left_to_explore, "partition": f"locality-order position range x{world}" if sharded else "single GPU",
                        "oracle_digest_asserted": digest_checked,
+                       # the digests are generated by the CPU restatement (oracle/make_digests.py); where oracle/pin_reference.py has run the REFERENCE BINARY on
+                       # the same reads, its P.graph3 (md5, size) and log counters are in the digest too and equal the restatement's
+                       "oracle_digest_generated_by": (want or {}).get("generated_by"),
+                       "oracle_digest_pinned_by_reference_binary": bool((want or {}).get("reference_binary_graph3_identical")),
                        "timed_region": "index build + initial pass + reduce + sort/convert; reads resident in HBM"},
             "phases_ms": {kph: v / args.steps for kph, v in phase.items()},
             "reads_per_s": st.unique_reads / (elapsed / args.steps),
@@ -384,7 +431,7 @@ def main():
             if res["cpu_baseline"]:
                 res["speedup_vs_cpu_baseline"] = value / res["cpu_baseline"]["value"]
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if sharded:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -119,7 +119,10 @@ Device* dev_create(int ordinal, std::string& err) {
       if (hipMemcpyToSymbol(HIP_SYMBOL(g_tag_mask), &mask, sizeof mask) != hipSuccess) { err = "tag mask upload failed"; delete d; return nullptr; }
       const char* mb = getenv("SAGE2OV_TEST_MTAG_BITS"); const int nm = mb ? atoi(mb) : 24;
       const u32 mmask = (nm >= 1 && nm < 24) ? ((1u << nm) - 1u) : 0xFFFFFFu;
-      if (hipMemcpyToSymbol(HIP_SYMBOL(g_mtag_mask), &mmask, sizeof mmask) != hipSuccess) { err = "tag mask upload failed"; delete d; return nullptr; } }
+      if (hipMemcpyToSymbol(HIP_SYMBOL(g_mtag_mask), &mmask, sizeof mmask) != hipSuccess) { err = "tag mask upload failed"; delete d; return nullptr; }
+      const char* fb = getenv("SAGE2OV_TEST_FP_BITS"); const int nf = fb ? atoi(fb) : 20;
+      const u32 fmask = (nf >= 0 && nf < 20) ? ((1u << nf) - 1u) : 0xFFFFFu;
+      if (hipMemcpyToSymbol(HIP_SYMBOL(g_fp_mask), &fmask, sizeof fmask) != hipSuccess) { err = "fingerprint mask upload failed"; delete d; return nullptr; } }
     for (auto& ev : d->ev) hipEventCreate(&ev);
     if (hipMalloc(&d->d_counters, 24 * sizeof(u64)) != hipSuccess) { err = "hipMalloc(counters) failed"; delete d; return nullptr; }
     hipMemset(d->d_counters, 0, 24 * sizeof(u64));
@@ -171,7 +174,9 @@ static int partition_by_window(Device* d, PtBufs& B, bool hasP, bool hasM, u32 n
 int dev_organize_reads(Device* d, const uint64_t* pool, uint64_t pool_words, const uint64_t* off, const uint16_t* len, uint64_t n, int S, int minL, int maxL, int k,
                        uint64_t* N_out, std::vector<uint64_t>& words_out, std::vector<uint16_t>& freq_out, std::string& err, OrgAscii* ascii) {
     HIPCHK(hipSetDevice(d->ordinal));
-    hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    struct EvPair { hipEvent_t a = nullptr, b = nullptr; ~EvPair() { if (a) hipEventDestroy(a); if (b) hipEventDestroy(b); } } evp;   // (destroyed on every return path)
+    HIPCHK(hipEventCreate(&evp.a)); HIPCHK(hipEventCreate(&evp.b));
+    const hipEvent_t e0 = evp.a, e1 = evp.b;
     HIPCHK(hipEventRecord(e0, d->stream));
     // ASCII input (sage2ov_reads_add_ascii): filter, 2-bit pack and canonical orientation on the device (utils.cpp:144-166, :96-119, readLoader.cpp:195)
     unsigned char* dbases = nullptr; u64* doffA = nullptr; u32* gflag = nullptr; u32* gpos = nullptr;
@@ -251,7 +256,7 @@ int dev_organize_reads(Device* d, const uint64_t* pool, uint64_t pool_words, con
     HIPCHK(hipMemcpyAsync(words_out.data(), reads, (N + 1) * S * sizeof(u64), hipMemcpyDeviceToHost, d->stream));
     HIPCHK(hipMemcpyAsync(freq_out.data(), dfreq, (N + 1) * sizeof(unsigned short), hipMemcpyDeviceToHost, d->stream));
     HIPCHK(hipStreamSynchronize(d->stream));
-    float ms = 0; hipEventElapsedTime(&ms, e0, e1); d->tm.organize_ms += ms; hipEventDestroy(e0); hipEventDestroy(e1);
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1); d->tm.organize_ms += ms;
     hipFree(dfreq);
     // the organised store becomes the context's read store (same state as after dev_upload_reads)
     free_reads(d);
@@ -395,7 +400,7 @@ int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t
         HIPCHK(hipMemcpyAsync(c, d->d_counters + 8, sizeof c, hipMemcpyDeviceToHost, d->stream));
         HIPCHK(hipStreamSynchronize(d->stream));
         lap("table windows");
-        if (c[8]) { err = "index build: a key occurs in more than 16 M reads, or a table window overflowed"; return SAGE2OV_ERR_LIMIT; }
+        if (c[8]) { err = "index build: a key occurs in more than 1 M reads, or a table window overflowed"; return SAGE2OV_ERR_LIMIT; }
         if (c[2] > big_cap) { err = "too many long buckets"; return SAGE2OV_ERR_LIMIT; }
         if (c[2]) {
             hipLaunchKernelGGL(k_index_purity, dim3(grid_for(c[2] * 64, 256)), dim3(256), 0, d->stream, d->readsLoc, d->S, d->h, big, c[2], d->csr, d->d_counters + 8);
@@ -797,6 +802,13 @@ struct HugeBuf {
     ~HugeBuf() { if (p) { if (registered) hipHostUnregister(p); munmap(p, bytes); } }
 };
 constexpr u32 XO_MARK = 0x80000000u, XO_RK = 0x7FFFFFFFu, XO_IDM = 0x3FFFFFFFu;
+#if defined(__x86_64__)
+static inline void xo_relax() { __builtin_ia32_pause(); }
+static inline u64 xo_ticks() { return __builtin_ia32_rdtsc(); }
+#else
+static inline void xo_relax() { std::this_thread::yield(); }
+static inline u64 xo_ticks() { return (u64)std::chrono::steady_clock::now().time_since_epoch().count(); }
+#endif
 struct XoScalar {
     static inline u32 next_unexplored(const u32* plist, u32 x, u32 n, const u32* rank) {      // kind != 2 and rank[to] == 0
         for (; x < n; x++) { const u32 e = plist[x]; if ((e >> 30) != 2u && rank[e & XO_IDM] == 0) return x; }
@@ -874,6 +886,10 @@ static void explore_order_impl(const std::vector<u32>& pos, const std::vector<co
             // (it shares the walk's issue slots), no helper 3.3 s -- so the neighbour core is tried first
             if (!getenv("SAGE2OV_WALK_SMT_SIBLING")) { const int nb = (me & ~7) | ((me + 1) & 7); cpu_set_t al; CPU_ZERO(&al); if (sched_getaffinity(0, sizeof al, &al) == 0 && CPU_ISSET(nb, &al)) sib = nb; } }
         cpu_set_t allowed; CPU_ZERO(&allowed); if (sib >= 0 && (sched_getaffinity(0, sizeof allowed, &allowed) != 0 || !CPU_ISSET(sib, &allowed))) sib = -1;
+        // Pinning (this thread to its current core for the duration of the walk, the helper to a neighbour) is what the 1.9 s were measured with, but a library
+        // call should not fight over cores with other ranks of the same job: off by default when a launcher started several local ranks
+        // (LOCAL_WORLD_SIZE > 1), SAGE2OV_WALK_PIN=0/1 decides otherwise.  Without it the helper still runs, wherever the scheduler puts it.
+        { const char* pe = getenv("SAGE2OV_WALK_PIN"); const char* lw = getenv("LOCAL_WORLD_SIZE"); const bool pin = pe ? atoi(pe) != 0 : !(lw && atoi(lw) > 1); if (!pin) sib = -1; }
         if (sib >= 0 && pthread_getaffinity_np(pthread_self(), sizeof savedMask, &savedMask) == 0) { cpu_set_t one; CPU_ZERO(&one); CPU_SET(me, &one); pinnedMain = pthread_setaffinity_np(pthread_self(), sizeof one, &one) == 0; }   // (restored when the walk ends)
         static const int AHEAD = getenv("SAGE2OV_WALK_AHEAD") ? atoi(getenv("SAGE2OV_WALK_AHEAD")) : 4, WINDOW = 24;
         helper = std::thread([&, sib]() {
@@ -882,7 +898,7 @@ static void explore_order_impl(const std::vector<u32>& pos, const std::vector<co
             while (!walkDone.load(std::memory_order_acquire)) {
                 const size_t s0 = popPos.load(std::memory_order_relaxed), e0 = queue.pub.load(std::memory_order_acquire);
                 size_t a = std::max(done, s0 + (size_t)AHEAD), b = std::min(e0, s0 + (size_t)AHEAD + WINDOW);
-                if (a >= b) { __builtin_ia32_pause(); continue; }
+                if (a >= b) { xo_relax(); continue; }
                 for (size_t i = a; i < b; i++) {
                     const PL nx = pl[queue.d[i]]; const u32* q = nx.p; if (!q) continue;
                     for (u32 x = 0; x < nx.n; x++) {
@@ -901,13 +917,13 @@ static void explore_order_impl(const std::vector<u32>& pos, const std::vector<co
     u64 stPops = 0, stMarks = 0, stScanA = 0, stScanB = 0, stAnyFalse = 0, stEvB = 0, stStarts = 0; const bool stats = getenv("SAGE2OV_TIMING") != nullptr;
     auto explore_neighbours = [&](u32 r) {                                       // every still unexplored neighbour this read sees, in list order (:531-541)
         const u32* plist = pl[r].p; const u32 en = pl[r].n; stMarks++; stScanA += en;
-        const u64 t0_ = stats ? __builtin_ia32_rdtsc() : 0;
+        const u64 t0_ = stats ? xo_ticks() : 0;
         for (u32 x = F::next_unexplored(plist, 0, en, rank); x < en; x = F::next_unexplored(plist, x + 1, en, rank)) {
-            const u32 to = plist[x] & XO_IDM; rank[to] = ++ctr; queue.push_back(to);
+            const u32 to = plist[x] & XO_IDM; __atomic_store_n(&rank[to], ++ctr, __ATOMIC_RELAXED); queue.push_back(to);
             static const int PFE = getenv("SAGE2OV_WALK_PFE") ? atoi(getenv("SAGE2OV_WALK_PFE")) : 1;
             if (PFE) { const PL& t = pl[to]; if (t.p) { __builtin_prefetch(t.p); __builtin_prefetch(t.p + 16); __builtin_prefetch(t.p + 32); __builtin_prefetch(t.p + 48); } }   // it is marked (its list scanned) within a few pops
         }
-        if (stats) tcA += __builtin_ia32_rdtsc() - t0_;
+        if (stats) tcA += xo_ticks() - t0_;
     };
     for (u32 p0 : startOrder) {                                                  // ascending ids, as the serial loop starts its searches
         if (!(pl[p0].cand & 2u) || rank[p0] != 0) continue;
@@ -915,23 +931,23 @@ static void explore_order_impl(const std::vector<u32>& pos, const std::vector<co
         while (start < queue.size()) {
             const u32 r1 = queue[start++]; stPops++; popPos.store(start, std::memory_order_relaxed);
             if (start + 8 < queue.size()) { const PL& nx = pl[queue[start + 8]]; if (nx.p) for (u32 o = 0; o < nx.n; o += 16) __builtin_prefetch(nx.p + o); }   // the popped read's own list, 8 pops ahead
-            const u64 t1_ = stats ? __builtin_ia32_rdtsc() : 0;
-            if (rank[r1] == 0) rank[r1] = ++ctr;
+            const u64 t1_ = stats ? xo_ticks() : 0;
+            if (rank[r1] == 0) __atomic_store_n(&rank[r1], ++ctr, __ATOMIC_RELAXED);
             const u32 rw = rank[r1] & XO_RK, e1 = pl[r1].n; const u32* plist = pl[r1].p;
             bool any = (pl[r1].cand & 1u) != 0;
             for (u32 x = 0; !any && x < e1; x++) any = present(rw, plist[x]);
-            if (stats) tcB += __builtin_ia32_rdtsc() - t1_;
+            if (stats) tcB += xo_ticks() - t1_;
             if (!any) { stAnyFalse++; continue; }                                // an empty list (:527)
-            if (!(rank[r1] & XO_MARK)) { explore_neighbours(r1); rank[r1] |= XO_MARK; }
+            if (!(rank[r1] & XO_MARK)) { explore_neighbours(r1); __atomic_store_n(&rank[r1], rank[r1] | XO_MARK, __ATOMIC_RELAXED); }
             stScanB += e1;
-            const u64 t2_ = stats ? __builtin_ia32_rdtsc() : 0; const u64 a0_ = tcA;
+            const u64 t2_ = stats ? xo_ticks() : 0; const u64 a0_ = tcA;
             // (:543-561) neighbours that are explored but not yet marked
             for (u32 x = F::next_unmarked(plist, 0, e1, rank); x < e1; x = F::next_unmarked(plist, x + 1, e1, rank)) {
                 const u32 e = plist[x], r2 = e & XO_IDM, k = e >> 30, rt = rank[r2] & XO_RK;
                 if (k == 1 ? !(rt > rw) : (k == 2 ? !(rt < rw) : false)) continue;  // not in this read's list
-                explore_neighbours(r2); rank[r2] |= XO_MARK; stEvB++;
+                explore_neighbours(r2); __atomic_store_n(&rank[r2], rank[r2] | XO_MARK, __ATOMIC_RELAXED); stEvB++;
             }
-            if (stats) tcC += (__builtin_ia32_rdtsc() - t2_) - (tcA - a0_);
+            if (stats) tcC += (xo_ticks() - t2_) - (tcA - a0_);
         }
     }
     if (stats) fprintf(stderr, "[walk] Mcycles: explore_neighbours %llu, pop head + any %llu, second loop (without the explores) %llu\n", (unsigned long long)(tcA >> 20), (unsigned long long)(tcB >> 20), (unsigned long long)(tcC >> 20));

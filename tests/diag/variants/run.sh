@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: run.sh name...   -> bench each variants/libsage2ov_<name>.so (no CPU baseline), one line each
 for v in "$@"; do
-  SAGE2OV_LIB=/root/repo/variants/libsage2ov_$v.so timeout -k 10 200 python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-noisy-variant 2>/dev/null | python3 -c "
+  SAGE2OV_LIB=$PWD/tests/diag/variants/build/libsage2ov_$v.so timeout -k 10 200 python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-noisy-variant 2>/dev/null | python3 -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):

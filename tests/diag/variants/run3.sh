@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: run3.sh name...  -> configs[2] headline (no side workloads) with variants/libsage2ov_<name>.so, one line each
 for v in "$@"; do
-  SAGE2OV_LIB=$PWD/variants/libsage2ov_$v.so timeout -k 10 300 python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-noisy-variant --no-c2 --no-step4 2>/dev/null | python3 -c "
+  SAGE2OV_LIB=$PWD/tests/diag/variants/build/libsage2ov_$v.so timeout -k 10 300 python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-noisy-variant --no-c2 --no-step4 2>/dev/null | python3 -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):

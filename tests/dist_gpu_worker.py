@@ -1,5 +1,7 @@
 """Worker for tests/test_gpu_dist.py: sage2_amd.dist.run_steps23_sharded end to end with `world` ranks that share cuda:0 (collectives
-staged through gloo: the code path of the multi-GPU bench minus RCCL).  Every rank must end with the reference's P.graph3."""
+staged through gloo: the code path of the multi-GPU bench minus RCCL), or -- backend "nccl", one rank -- with every collective on
+RCCL and device tensors (RCCL refuses two ranks on one GPU, so that is the largest world a one-GPU box can run).  Every rank must end
+with the reference's P.graph3."""
 import os
 import sys
 
@@ -16,9 +18,13 @@ from sage2_amd.dist import run_steps23_sharded   # noqa: E402
 
 def main():
     name, out = sys.argv[1], sys.argv[2]
-    dist.init_process_group("gloo")
-    rank, world = dist.get_rank(), dist.get_world_size()
+    backend = sys.argv[3] if len(sys.argv) > 3 else "gloo"
     dev = torch.device("cuda", 0); torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
     m = fx.golden(name)
     bases, off = fx.make_reads(m["synth"])
     ctx = s2.Context(m["k"], device=0, rank=rank, world=world)
@@ -29,9 +35,9 @@ def main():
     ok = open(gp, "rb").read() == fx.golden_graph3(name)
     st = ctx.overlap_stats()
     ok = ok and st.contained_extension == m["counters"]["contained_extension"] and st.contained_size == m["counters"]["contained_size"]
-    t = torch.tensor([1 if ok else 0]); dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    t = torch.tensor([1 if ok else 0], device=dev if backend == "nccl" else "cpu"); dist.all_reduce(t, op=dist.ReduceOp.MIN)
     if rank == 0:
-        print("DIST_GPU_OK" if int(t.item()) == 1 else "DIST_GPU_MISMATCH", world, flush=True)
+        print("DIST_GPU_OK" if int(t.item()) == 1 else "DIST_GPU_MISMATCH", world, dist.get_backend(), flush=True)
     ctx.close()
     dist.destroy_process_group()
 

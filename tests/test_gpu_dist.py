@@ -19,3 +19,47 @@ def test_run_steps23_sharded_matches_reference(name, world, tmp_path):
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, timeout=600)
     out = r.stdout.decode()
     assert r.returncode == 0 and f"DIST_GPU_OK {world}" in out, out[-3000:]
+
+
+@pytest.mark.parametrize("name", ["g5_mixedlen_k21", "g3_noisy_rep_k21", "g4_highcopy_k21"])
+def test_run_steps23_sharded_on_rccl_one_rank(name, tmp_path):
+    """backend "nccl" (= RCCL): the device-tensor branches of sage2_amd/dist.py -- all-gather of records and edge buckets, MAX all-reduce of the
+    containment planes -- execute on RCCL itself, with the one rank a one-GPU box allows.  Same files as the reference's."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(ROOT, "tests", "dist_gpu_worker.py"), name, str(tmp_path), "nccl"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, timeout=600)
+    out = r.stdout.decode()
+    assert r.returncode == 0 and "DIST_GPU_OK 1 nccl" in out, out[-3000:]
+
+
+def test_bench_sharded_path_on_rccl_one_rank():
+    """bench.py under torchrun with one rank and the multi-rank path forced (process group on RCCL, broadcast of the read store, the three
+    exchanges): its edge-list crc must equal the single-context run's, and the JSON must say what ran."""
+    import json
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", SAGE2OV_BENCH_FORCE_SHARDED="1")
+    common = ["--steps", "1", "--warmup", "1", "--reads", "200000", "--no-cpu-baseline", "--no-noisy-variant", "--no-c2", "--no-step4"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1", "--master-port", "29543",
+           os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    a = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    assert a["collectives"] == "nccl" and a["world_size"] == 1 and a["config"]["partition"].startswith("locality-order position range")
+    env1 = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env1, timeout=900)
+    assert r1.returncode == 0, r1.stderr.decode()[-3000:]
+    b = json.loads([ln for ln in r1.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    assert b["collectives"] is None and a["config"]["edges_crc32"] == b["config"]["edges_crc32"] and a["config"]["verified_overlaps"] == b["config"]["verified_overlaps"]
+
+
+def test_bench_starts_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment: bench.py itself starts one child per rank (the parent never touches the
+    GPU) and relays rank 0's line, which must say two ranks ran.  Both ranks share the one GPU here, so the collectives are staged through gloo."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(SAGE2OV_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--reads", "200000",
+                        "--no-cpu-baseline", "--no-noisy-variant", "--no-c2", "--no-step4"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    a = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    assert a["n_gpus"] == 2 and a["world_size"] == 2 and a["collectives"] == "gloo"

@@ -1,5 +1,6 @@
 """GPU: the HIP path (through the C ABI) against (a) the reference's own golden files, byte for byte, and
 (b) the oracle's per-read intermediate results, bit for bit, on the same seeded inputs."""
+import os
 import numpy as np
 import pytest
 
@@ -278,6 +279,27 @@ def test_cli_steps_1_to_3_write_reference_files(tmp_path):
     want = fx.golden_graph3("g6_k70_150").split(b"\n", 3)
     assert got[3] == want[3]          # edge records identical (the 3 header lines need the FASTA totals, which P.reads lacks)
     assert os.path.exists(os.path.join(out, "t.log"))
+    # `-M 2 -s` (main.cpp:63-90): steps 1-2 on the GPU, P.reads and P.hashTable -- the slot-by-slot dump of the reference's own double-hashed table
+    # (hashTable.cpp:256-273) -- as the reference binary wrote them for these reads
+    subprocess.run([cli, "-f", fa, "-k", str(m["k"]), "-o", out, "-p", "h", "-M", "2", "-s"], check=True)
+    assert fx.md5_file(os.path.join(out, "h.reads")) == m["reads_md5"]
+    assert os.path.getsize(os.path.join(out, "h.hashTable")) == m["hashtable_size"] and fx.md5_file(os.path.join(out, "h.hashTable")) == m["hashtable_md5"]
+
+
+@pytest.mark.parametrize("name", ["g1_clean100_k21", "g4_highcopy_k21", "g5_mixedlen_k21"])
+def test_hashtable_file_from_a_device_organised_context(name, tmp_path):
+    """SURVEY 8f-4 on the GPU path: reads organised ON THE DEVICE (ids, order, dedupe from k_org_*), index built, and P.hashTable written from that
+    context must be the reference binary's file (md5 + size recorded by oracle/make_golden.py) -- g4 has 250 long buckets (the N+100 marker and the
+    101-entry cap, hashTable.cpp:111-123,178), g5 mixed read lengths."""
+    m = fx.golden(name)
+    bases, off = fx.make_reads(m["synth"])
+    c = s2.Context(m["k"], device=0)
+    c.reads_add_ascii(bases, off); c.reads_organize(); c.index_build()
+    assert c.timings().organize_ms > 0                       # step 1 really ran on the device
+    p = str(tmp_path / "t.hashTable"); c.hashtable_save(p)
+    assert int(open(p).readline()) == m["counters"]["hash_table_size"]
+    assert os.path.getsize(p) == m["hashtable_size"] and fx.md5_file(p) == m["hashtable_md5"]
+    c.close()
 
 
 @pytest.mark.parametrize("pd,k", [

@@ -51,7 +51,10 @@ if pk:
         import re
         m = re.match(r"(\d+) x (\d+) bp .*?k=(\d+).*?seed (\d+)", bench["config"]["workload"])
         key = f"{m.group(1)}x{m.group(2)}_k{m.group(3)}_seed{m.group(4)}"
-        cur[key] = {"bytes_per_launch": rd_bytes + w * 1024.0, "read_bytes": rd_bytes, "write_bytes": w * 1024.0, "fetch_KiB_as_reported": f, "write_KiB": w,
+        import hashlib
+        src_sha = hashlib.sha1(b"".join(open(os.path.join(root, "sage2_amd", "csrc", n), "rb").read() for n in ("kernels_probe_fast.inc", "kernels_common.inc"))).hexdigest()
+        cur[key] = {"kernel_source_sha1": src_sha,     # bench.py reports this traffic only while the kernel's source is the one that was profiled
+                    "bytes_per_launch": rd_bytes + w * 1024.0, "read_bytes": rd_bytes, "write_bytes": w * 1024.0, "fetch_KiB_as_reported": f, "write_KiB": w,
                     "read_requests_128B": r128, "kernel": k, "source": f"profiles/{tag}_pmc_summary.txt",
                     "note": "per probe pass (sum over the pass's launches of the kernel); reads = TCC_EA0_RDREQ_128B x 128 B (all read requests are 128-byte lines; FETCH_SIZE tallies them at 64 B, cf. MI355X_MICROARCH.md HBM section)"}
         json.dump(cur, open(tj, "w"), indent=1)
