@@ -206,6 +206,16 @@ int sage2ov_shard_edges_count(const sage2ov_ctx* ctx, uint64_t* n);
 int sage2ov_shard_edges_export(sage2ov_ctx* ctx, void* dev_dst, uint64_t cap_edges);
 int sage2ov_shard_edges_set(sage2ov_ctx* ctx, const void* dev_src, uint64_t n_edges);
 
+/* Sharded reduce phase (round 3).  On a context with world > 1, sage2ov_overlap_reduce (buildOverlapGraphEconomy, economyGraph.cpp:495-574) builds the hit
+ * lists and the adjacency of ALL unresolved reads -- every rank's marks read them -- but runs markTransitiveEdge / removeTransitiveEdges (:643-707) and the
+ * re-emission of the surviving edges only for THIS RANK'S SHARE of the unresolved reads (a contiguous part of their list; any cut is exact: a read's marks
+ * are a function of the lists).  The survivors of the share are this rank's survivor bucket (16-byte records like the edge buckets): all-gather the buckets,
+ * sum `removed_partial` over the ranks, and hand every rank the concatenation before sage2ov_overlap_convert (which refuses to run without it).
+ * Where the phase runs replicated (the serial replay for a handful of reads), rank 0's bucket carries everything and the others are empty. */
+int sage2ov_shard_survivors_count(const sage2ov_ctx* ctx, uint64_t* n, uint64_t* removed_partial);
+int sage2ov_shard_survivors_export(sage2ov_ctx* ctx, void* dev_dst, uint64_t cap_edges);
+int sage2ov_shard_survivors_set(sage2ov_ctx* ctx, const void* dev_src, uint64_t n_total, uint64_t removed_total);
+
 /* ---- profiling hooks: HIP-event timings of the last run, milliseconds ---- */
 typedef struct sage2ov_timings {
     double index_ms, probe_ms, reciprocal_ms, reduce_ms, convert_ms, total_ms;
@@ -215,6 +225,9 @@ typedef struct sage2ov_timings {
     double organize_ms;          /* step 1 on the device: upload of the staged reads .. organised read store resident (HIP events) */
     uint64_t probe_fast_launches;     /* launches of the fast kernel behind probe_kernel_ms: a pass is a sample launch, the rest of the range
                                          and, if reads were listed, one launch over the list */
+    /* what a multi-rank run keeps replicated / shards inside the two phases above (bench.py's scaling model): */
+    double reciprocal_cond_ms;        /* the part of reciprocal_ms every rank spends on ALL reads (cond(i), economyGraph.cpp:460); the rest is the emit half, sharded */
+    double reduce_marks_ms;           /* the part of reduce_ms spent in the marks + removals + re-emission (economyGraph.cpp:643-707): sharded over the ranks */
 } sage2ov_timings;
 int sage2ov_timings_get(const sage2ov_ctx* ctx, sage2ov_timings* out);
 int sage2ov_timings_reset(sage2ov_ctx* ctx);

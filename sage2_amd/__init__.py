@@ -48,7 +48,7 @@ class SimplifyStats(C.Structure):
 class Timings(C.Structure):
     _fields_ = [("index_ms", C.c_double), ("probe_ms", C.c_double), ("reciprocal_ms", C.c_double), ("reduce_ms", C.c_double),
                 ("convert_ms", C.c_double), ("total_ms", C.c_double), ("probe_kernel_ms", C.c_double), ("probe_kernel_launches", C.c_uint64), ("sequential_reads", C.c_uint64),
-                ("organize_ms", C.c_double), ("probe_fast_launches", C.c_uint64)]
+                ("organize_ms", C.c_double), ("probe_fast_launches", C.c_uint64), ("reciprocal_cond_ms", C.c_double), ("reduce_marks_ms", C.c_double)]
 
 
 class SynthParams(C.Structure):
@@ -337,3 +337,15 @@ class Context:
 
     def shard_edges_set(self, dev_ptr, n):
         self._chk(lib().sage2ov_shard_edges_set(self._h, C.c_void_p(dev_ptr), C.c_uint64(n)))
+
+    # sharded reduce phase: this rank's survivor bucket (count, removals of its share), export, and the concatenation of all ranks' buckets back in
+    def shard_survivors_count(self):
+        n, rem = C.c_uint64(), C.c_uint64()
+        self._chk(lib().sage2ov_shard_survivors_count(self._h, C.byref(n), C.byref(rem)))
+        return n.value, rem.value
+
+    def shard_survivors_export(self, dev_ptr, cap):
+        self._chk(lib().sage2ov_shard_survivors_export(self._h, C.c_void_p(dev_ptr), C.c_uint64(cap)))
+
+    def shard_survivors_set(self, dev_ptr, n_total, removed_total):
+        self._chk(lib().sage2ov_shard_survivors_set(self._h, C.c_void_p(dev_ptr), C.c_uint64(n_total), C.c_uint64(removed_total)))

@@ -168,7 +168,7 @@ int dev_upload_reads(Device* d, const uint64_t* words, uint64_t N, int S, int mi
 
 static int scan_u32(Device* d, const u32* in, u64 n, u32* out, u64* total, std::string& err);
 struct PtBufs { u32* K[2]; u64* P[2]; u32* M[2]; };
-static int partition_by_window(Device* d, PtBufs& B, bool hasP, bool hasM, u32 n, int shiftW, u64 nWin, bool digit0Counted, u32* cnt, u32* base, u32* off, int* cur_out, std::string& err);
+static int partition_by_window(Device* d, PtBufs& B, bool hasP, bool hasM, u32 n, int shiftW, u64 nWin, bool digit0Counted, u32* cnt, u32* base, u32* off, int* cur_out, std::string& err, bool keyFromP = false);
 // Step 1 on the device: see k_org_canon.  On return the read store is resident exactly as after dev_upload_reads, and the
 // host receives the image (for the .reads writer, lengths) and the frequencies.
 int dev_organize_reads(Device* d, const uint64_t* pool, uint64_t pool_words, const uint64_t* off, const uint16_t* len, uint64_t n, int S, int minL, int maxL, int k,
@@ -272,14 +272,23 @@ int dev_organize_reads(Device* d, const uint64_t* pool, uint64_t pool_words, con
 
 static int build_locality_order(Device* d, u64 lo, u64 hi, const u64** order_out, std::string& err);
 // The locality-ordered copy of the read store + the two translation tables (see Device::readsLoc).  Part of the index build (timed with it).
-__global__ void k_loc_store(const u64* __restrict__ reads, const u64* __restrict__ order, u64 N, int S, u64* out, u32* idOf, u32* posOf, unsigned short* meta) {
-    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < (u64)S) out[t] = 0ull;                                                      // slot 0: zeros (the target of gated-off gathers)
-    if (t == 0) { idOf[0] = 0; posOf[0] = 0; idOf[N + 1] = 0; posOf[N + 1] = 0; meta[0] = 0xFFFF; meta[N + 1] = 0xFFFF; }
-    if (t >= N * S) return;
-    const u64 p = t / S; const int c = (int)(t % S); const u64 o = order ? order[p] : (u64)(p + 1) | (0xFFFFull << 32); const u32 id = (u32)o;
-    out[(p + 1) * S + c] = reads[(u64)id * S + c];
-    if (c == 0) { idOf[p + 1] = id; posOf[id] = (u32)(p + 1); meta[p + 1] = (unsigned short)(o >> 32); }   // meta 0xFFFF: no minimiser information (no window reuse)
+// Round 3: two kernels.  k_loc_index writes the translation tables from the order; k_loc_scatter then STREAMS the id-ordered store (coalesced reads) and
+// writes every slot to its position (whole 32 / 64 / 128-byte slots: no read-modify-write at the memory side).  The gather it replaces pulled every
+// 64-byte slot as a 128-byte line request: 5.4 GB of reads for 2.7 GB of reads at configs[2].
+__global__ void k_loc_index(const u64* __restrict__ order, u64 N, u32* idOf, u32* posOf, unsigned short* meta) {
+    const u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p == 0) { idOf[0] = 0; posOf[0] = 0; idOf[N + 1] = 0; posOf[N + 1] = 0; meta[0] = 0xFFFF; meta[N + 1] = 0xFFFF; }
+    if (p >= N) return;
+    const u64 o = order ? order[p] : (u64)(p + 1) | (0xFFFFull << 32); const u32 id = (u32)o;
+    idOf[p + 1] = id; posOf[id] = (u32)(p + 1); meta[p + 1] = (unsigned short)(o >> 32);       // meta 0xFFFF: no minimiser information (no window reuse)
+}
+__global__ void k_loc_scatter(const u64* __restrict__ reads, const u32* __restrict__ posOf, u64 N, int S, u64* out) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;      // one 16-byte piece of a slot per thread
+    const int H = S / 2;
+    if (t >= (N + 1) * H) return;
+    const u64 id = t / H; const int c = (int)(t % H);
+    const ulonglong2 v = ((const ulonglong2*)reads)[t];            // (slot 0 is all zero and stays at position 0: posOf[0] = 0)
+    ((ulonglong2*)out)[(u64)posOf[id] * H + c] = v;
 }
 __global__ void k_status_by_pos(const u32* __restrict__ idOf, const uint8_t* __restrict__ status, u64 N, uint8_t* statusP) {
     const u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x; if (p > N) return; statusP[p] = p ? status[idOf[p]] : (uint8_t)0xFF;
@@ -292,7 +301,8 @@ static int build_locality_store(Device* d, std::string& err) {
     d->readsLoc = rl; d->idOf = io; d->posOf = po; d->statusP = sp; d->metaP = me;
     const u64* order = nullptr;
     if (N && !getenv("SAGE2OV_NO_LOCALITY")) { int rc = build_locality_order(d, 1, N + 1, &order, err); if (rc) return rc; }
-    hipLaunchKernelGGL(k_loc_store, dim3(grid_for(std::max<u64>(N * d->S, d->S), 256)), dim3(256), 0, d->stream, d->reads, order, (u64)N, d->S, rl, io, po, me);
+    hipLaunchKernelGGL(k_loc_index, dim3(grid_for(std::max<u64>(N, 1), 256)), dim3(256), 0, d->stream, order, (u64)N, io, po, me);
+    hipLaunchKernelGGL(k_loc_scatter, dim3(grid_for((N + 1) * (d->S / 2), 256)), dim3(256), 0, d->stream, d->reads, po, (u64)N, d->S, rl);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -310,7 +320,8 @@ static int pt_digits(u64 nWin, int* bits, int* nd) {            // window id bit
     int wb = 0; while ((1ull << wb) < nWin) wb++;
     *bits = wb; *nd = wb == 0 ? 0 : (wb + 8) / 9; return 0;
 }
-static int partition_by_window(Device* d, PtBufs& B, bool hasP, bool hasM, u32 n, int shiftW, u64 nWin, bool digit0Counted, u32* cnt, u32* base, u32* off, int* cur_out, std::string& err) {
+// keyFromP: the digits come from the HIGH WORD of P instead of K (K rides along); no window bounds in that form.
+static int partition_by_window(Device* d, PtBufs& B, bool hasP, bool hasM, u32 n, int shiftW, u64 nWin, bool digit0Counted, u32* cnt, u32* base, u32* off, int* cur_out, std::string& err, bool keyFromP) {
     int wb, nd; pt_digits(nWin, &wb, &nd);
     const u32 ntiles = (u32)((n + PT_TILE - 1) / PT_TILE);
     int cur = 0;
@@ -318,15 +329,16 @@ static int partition_by_window(Device* d, PtBufs& B, bool hasP, bool hasM, u32 n
         const int bper = nd ? (wb + nd - 1) / nd : 0;
         for (int j = 0; j < nd; j++) {
             const int shift = shiftW + j * bper; const int bj = std::min(bper, wb - j * bper); const u32 mask = (1u << bj) - 1u;
-            if (!(j == 0 && digit0Counted)) hipLaunchKernelGGL(k_pt_hist, dim3(ntiles), dim3(PT_THREADS), 0, d->stream, B.K[cur], n, shift, mask, cnt, ntiles);
+            if (!(j == 0 && digit0Counted)) hipLaunchKernelGGL(k_pt_hist, dim3(ntiles), dim3(PT_THREADS), 0, d->stream, keyFromP ? (const u32*)B.P[cur] + 1 : B.K[cur], n, shift, mask, cnt, ntiles, keyFromP ? 2u : 1u);
             int rc = scan_u32_async(d, cnt, (u64)(mask + 1) * ntiles, base, err); if (rc) return rc;
             const int o = cur ^ 1;
-            if (hasP && hasM) hipLaunchKernelGGL((k_pt_scatter<true, true>), dim3(ntiles), dim3(PT_THREADS), 0, d->stream, B.K[cur], B.P[cur], B.M[cur], n, shift, mask, base, ntiles, B.K[o], B.P[o], B.M[o]);
-            else if (hasP) hipLaunchKernelGGL((k_pt_scatter<true, false>), dim3(ntiles), dim3(PT_THREADS), 0, d->stream, B.K[cur], B.P[cur], (const u32*)nullptr, n, shift, mask, base, ntiles, B.K[o], B.P[o], (u32*)nullptr);
-            else hipLaunchKernelGGL((k_pt_scatter<false, true>), dim3(ntiles), dim3(PT_THREADS), 0, d->stream, B.K[cur], (const u64*)nullptr, B.M[cur], n, shift, mask, base, ntiles, B.K[o], (u64*)nullptr, B.M[o]);
+            if (keyFromP) hipLaunchKernelGGL((k_pt_scatter<true, false, true>), dim3(ntiles), dim3(PT_THREADS), 0, d->stream, B.K[cur], B.P[cur], (const u32*)nullptr, n, shift, mask, base, ntiles, B.K[o], B.P[o], (u32*)nullptr);
+            else if (hasP && hasM) hipLaunchKernelGGL((k_pt_scatter<true, true, false>), dim3(ntiles), dim3(PT_THREADS), 0, d->stream, B.K[cur], B.P[cur], B.M[cur], n, shift, mask, base, ntiles, B.K[o], B.P[o], B.M[o]);
+            else if (hasP) hipLaunchKernelGGL((k_pt_scatter<true, false, false>), dim3(ntiles), dim3(PT_THREADS), 0, d->stream, B.K[cur], B.P[cur], (const u32*)nullptr, n, shift, mask, base, ntiles, B.K[o], B.P[o], (u32*)nullptr);
+            else hipLaunchKernelGGL((k_pt_scatter<false, true, false>), dim3(ntiles), dim3(PT_THREADS), 0, d->stream, B.K[cur], (const u64*)nullptr, B.M[cur], n, shift, mask, base, ntiles, B.K[o], (u64*)nullptr, B.M[o]);
             cur = o;
         }
-        if (off) hipLaunchKernelGGL(k_pt_bounds, dim3(grid_for(n, 256)), dim3(256), 0, d->stream, B.K[cur], n, shiftW, (u32)nWin, off);
+        if (off && !keyFromP) hipLaunchKernelGGL(k_pt_bounds, dim3(grid_for(n, 256)), dim3(256), 0, d->stream, B.K[cur], n, shiftW, (u32)nWin, off);
     } else if (off) HIPCHK(hipMemsetAsync(off, 0, (nWin + 1) * sizeof(u32), d->stream));
     HIPCHK(hipGetLastError());
     *cur_out = cur;
@@ -491,13 +503,14 @@ static int build_locality_order(Device* d, u64 lo, u64 hi, const u64** order_out
     PtBufs B; B.M[0] = B.M[1] = nullptr;
     { WS(a, u32, WS_MINH, n + 4); B.K[0] = a; } { WS(a, u32, WS_OCUR, n + 4); B.K[1] = a; }
     { WS(a, u64, WS_ORDER, n + 4); B.P[0] = a; } { WS(a, u64, WS_OOFF, n + 4); B.P[1] = a; }
-    WS(mh, u32, WS_OCNT, n + 4); WS(mt, u32, WS_MICNT, n + 4);
     WS(cnt, u32, WS_PT_CNT, (u64)PT_NB_MAX * std::max<u32>(ntiles, 1) + 2); WS(base, u32, WS_PT_BASE, (u64)PT_NB_MAX * std::max<u32>(ntiles, 1) + 2);
-    hipLaunchKernelGGL(k_minimizer, dim3(grid_for(n, 256)), dim3(256), 0, d->stream, d->reads, (u64)lo, (u64)hi, d->S, mh, mt);
-    hipLaunchKernelGGL(k_order_pack, dim3(grid_for(n, 256)), dim3(256), 0, d->stream, mh, mt, (u64)n, (u64)lo, B.K[0], B.P[0]);
-    int cur = 0; int rc = partition_by_window(d, B, true, false, (u32)n, 0, 1ull << 9, false, cnt, base, nullptr, &cur, err); if (rc) return rc;
-    PtBufs C; C.M[0] = C.M[1] = nullptr; C.K[0] = B.K[cur ^ 1]; C.P[0] = B.P[cur ^ 1]; C.K[1] = B.K[cur]; C.P[1] = B.P[cur];
-    hipLaunchKernelGGL(k_order_rekey, dim3(grid_for(n, 256)), dim3(256), 0, d->stream, B.K[cur], B.P[cur], (u64)n, C.K[0], C.P[0]);
+    // K = the hash, P = meta << 32 | id, written by the minimiser kernel itself; pass 1 sorts by the meta (P's high word), passes 2-4 by the hash:
+    // one element format for all four passes (round 2 had a pack and a re-key kernel in between)
+    if (d->S == 4) hipLaunchKernelGGL((k_minimizer_t<4>), dim3(grid_for(n, 256)), dim3(256), 0, d->stream, d->reads, (u64)lo, (u64)hi, B.K[0], B.P[0]);
+    else if (d->S == 8) hipLaunchKernelGGL((k_minimizer_t<8>), dim3(grid_for(n, 256)), dim3(256), 0, d->stream, d->reads, (u64)lo, (u64)hi, B.K[0], B.P[0]);
+    else hipLaunchKernelGGL(k_minimizer, dim3(grid_for(n, 256)), dim3(256), 0, d->stream, d->reads, (u64)lo, (u64)hi, d->S, B.K[0], B.P[0]);
+    int cur = 0; int rc = partition_by_window(d, B, true, false, (u32)n, 0, 1ull << 9, false, cnt, base, nullptr, &cur, err, true); if (rc) return rc;
+    PtBufs C; C.M[0] = C.M[1] = nullptr; C.K[0] = B.K[cur]; C.P[0] = B.P[cur]; C.K[1] = B.K[cur ^ 1]; C.P[1] = B.P[cur ^ 1];
     int cur2 = 0; rc = partition_by_window(d, C, true, false, (u32)n, 32 - lg, 1ull << lg, false, cnt, base, nullptr, &cur2, err); if (rc) return rc;
     *order_out = C.P[cur2];
     return 0;
@@ -697,6 +710,27 @@ int dev_set_cands(Device* d, const void* src, uint64_t n, std::string& err) {   
     if (n) HIPCHK(hipMemcpyAsync(d->cand, src, n * sizeof(EdgeCand), hipMemcpyDeviceToDevice, d->stream));
     HIPCHK(hipStreamSynchronize(d->stream)); d->n_cand = n; return 0;
 }
+// survivor buckets of a sharded reduce phase: candidates [first, first + n) of the list (what this rank's marks re-emitted)
+int dev_export_cand_range(Device* d, void* dst, uint64_t first, uint64_t n, std::string& err) {
+    HIPCHK(hipSetDevice(d->ordinal));
+    if (first + n > d->n_cand) { err = "candidate range out of bounds"; return SAGE2OV_ERR_ARG; }
+    if (n) HIPCHK(hipMemcpyAsync(dst, d->cand + first, n * sizeof(EdgeCand), hipMemcpyDeviceToDevice, d->stream));
+    HIPCHK(hipStreamSynchronize(d->stream)); return 0;
+}
+// the list becomes its first `keep` candidates followed by the n candidates at src (device memory)
+int dev_replace_cand_tail(Device* d, uint64_t keep, const void* src, uint64_t n, std::string& err) {
+    HIPCHK(hipSetDevice(d->ordinal));
+    if (keep > d->n_cand) { err = "candidate range out of bounds"; return SAGE2OV_ERR_ARG; }
+    if (keep + n > d->cand_cap) {
+        EdgeCand* nc = nullptr; const u64 ncap = keep + n + 1024;
+        HIPCHK(hipMalloc(&nc, ncap * sizeof(EdgeCand)));
+        if (keep) HIPCHK(hipMemcpyAsync(nc, d->cand, keep * sizeof(EdgeCand), hipMemcpyDeviceToDevice, d->stream));
+        HIPCHK(hipStreamSynchronize(d->stream));
+        hipFree(d->cand); d->cand = nc; d->cand_cap = ncap;
+    }
+    if (n) HIPCHK(hipMemcpyAsync(d->cand + keep, src, n * sizeof(EdgeCand), hipMemcpyDeviceToDevice, d->stream));
+    HIPCHK(hipStreamSynchronize(d->stream)); d->n_cand = keep + n; return 0;
+}
 int dev_export_records(Device* d, void* dst, uint64_t lo, uint64_t hi, std::string& err) {
     HIPCHK(hipSetDevice(d->ordinal));
     if (hi > lo) hipLaunchKernelGGL(k_pack_records, dim3(grid_for(hi - lo, 256)), dim3(256), 0, d->stream, (u64)lo, (u64)hi, d->idOf, d->right, d->left, d->conn, d->cflag, (Record*)dst);
@@ -717,6 +751,7 @@ int dev_reciprocal(Device* d, uint64_t emit_lo, uint64_t emit_hi, uint64_t* n_ov
     HIPCHK(hipMemsetAsync(d->d_counters, 0, 8 * sizeof(u64), d->stream));
     HIPCHK(hipMemsetAsync(d->status, 0, N + 1, d->stream));
     hipLaunchKernelGGL(k_recip_cond, dim3(grid_for(N, 256 * COND_PER_THREAD)), dim3(256), 0, d->stream, N, d->right, d->left, d->conn, d->cflag, d->status, d->d_counters);
+    HIPCHK(hipEventRecord(d->ev[4], d->stream));
     if (emit_hi > emit_lo)
         hipLaunchKernelGGL(k_recip_emit, dim3(grid_for(emit_hi - emit_lo, 256 * EMIT_PER_THREAD)), dim3(256), 0, d->stream, N, d->reads, d->S, d->uniL, d->right, d->left, d->status, d->cand, d->cand_cap, d->d_counters, (u64)emit_lo, (u64)emit_hi);
     u64 c[8];
@@ -724,6 +759,7 @@ int dev_reciprocal(Device* d, uint64_t emit_lo, uint64_t emit_hi, uint64_t* n_ov
     HIPCHK(hipEventRecord(d->ev[1], d->stream));
     HIPCHK(hipStreamSynchronize(d->stream));
     float ms = 0; hipEventElapsedTime(&ms, d->ev[0], d->ev[1]); d->tm.reciprocal_ms += ms;
+    hipEventElapsedTime(&ms, d->ev[0], d->ev[4]); d->tm.recip_cond_ms += ms;
     if (c[0] > d->cand_cap) { err = "edge candidate buffer overflow"; return SAGE2OV_ERR_INTERNAL; }
     d->n_cand = c[0]; *n_ov = c[1]; *contained = c[2]; *contained_size = c[3];
     return 0;
@@ -965,7 +1001,12 @@ static void explore_order(const std::vector<u32>& pos, const std::vector<const u
     explore_order_impl<XoScalar>(pos, lists, lenp, hasCand, N, startOrder, rank);
 }
 
-int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved, uint64_t* n_hits, uint64_t* inserted, uint64_t* removed, int* done, std::string& err) {
+// Multi-rank contexts (shareRank / shareWorld): hit lists, adjacency and -- with long buckets -- the exploration order are computed for ALL unresolved
+// reads on every rank (they are read by everybody's marks), but the marks (:643-707), the removals and the re-emission of the surviving edges run for this
+// rank's share of the unresolved reads only (a contiguous part of the list): d->n_cand grows by this rank's survivors, *removed counts this rank's
+// removals; the caller all-gathers the survivor buckets (dev_export_survivors / dev_set_survivors) and sums the counters.
+int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved, uint64_t* n_hits, uint64_t* inserted, uint64_t* removed, int* done, std::string& err,
+                      uint32_t shareRank, uint32_t shareWorld) {
     HIPCHK(hipSetDevice(d->ordinal));
     *done = 0; *inserted = 0; *removed = 0; *n_hits = 0;
     const u64 N = d->N;
@@ -1167,17 +1208,23 @@ int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved
     else if (nslots) hipLaunchKernelGGL(k_ra_fill_h, dim3(grid_for(nslots, 256)), dim3(256), 0, d->stream, dh, (u64)nslots, offs, deg, hitcount, ent);
     if (ranked) { u64 c3[3]; HIPCHK(hipMemcpyAsync(c3, d->d_counters + 8, sizeof c3, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream)); present = c3[2]; }
     HIPCHK(hipMemsetAsync(d->d_counters + 8, 0, 4 * sizeof(u64), d->stream));
+    // this rank's share of the unresolved reads: entries [wlo, whi) of the list (any contiguous cut is exact: a read's marks depend on the lists only)
+    const u64 wlo = shareWorld > 1 ? nun * shareRank / shareWorld : 0, whi = shareWorld > 1 ? nun * (shareRank + 1) / shareWorld : nun;
+    const u32* const idsAll = ids; ids = ids + wlo; const u64 nunAll = nun; nun = whi - wlo; (void)idsAll; (void)nunAll;
     WS(svn, u32, WS_NEED, nun + 2); WS(svoff, u32, WS_OWNER, nun + 2);
-    const unsigned gb = (unsigned)std::min<u64>((nun + 3) / 4, 256ull * 16);
+    const unsigned gb = (unsigned)std::max<u64>(1, std::min<u64>((nun + 3) / 4, 256ull * 16));
     const u64 heavyCap = 1 << 16; WS(heavy, u32, WS_RA_HEAVY, heavyCap);
     WS(ent32, u32, WS_RA_ENT32, tot + 64); WS(split, u32, WS_RA_SPLIT, N + 2);
     hipLaunchKernelGGL(k_ra_pack32, dim3((unsigned)std::min<u64>((N + 4) / 4, 256ull * 64)), dim3(256), 0, d->stream, ent, offs, deg, (u64)N, ent32, split);
+    HIPCHK(hipEventRecord(d->ev[5], d->stream));                          // (marks_ms: the sharded part of the phase -- marks, removals, re-emission)
+    if (nun) {
     hipLaunchKernelGGL((k_ra_mark<128, 8, 0, false>), dim3(gb), dim3(256), 0, d->stream, ids, (u64)nun, offs, deg, ent, ent32, split, rm, svn, d->d_counters + 8, heavy, heavyCap);     // lists of <= 128 entries
     hipLaunchKernelGGL((k_ra_mark<RA_CAP, 10, 128, true>), dim3(gb), dim3(256), 0, d->stream, ids, (u64)nun, offs, deg, ent, ent32, split, rm, svn, d->d_counters + 8, heavy, heavyCap);   // 129 .. RA_CAP; longer: k_ra_mark_big
+    }
     u64 c[2];
     HIPCHK(hipMemcpyAsync(c, d->d_counters + 8, sizeof c, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
     HIPCHK(hipGetLastError());
-    if (c[0] > heavyCap) return 0;                                        // (never seen) that many oversized lists: serial replay
+    if (c[0] > heavyCap) { if (shareWorld > 1) { err = "reduce: too many oversized lists in this rank's share"; return SAGE2OV_ERR_LIMIT; } return 0; }   // (never seen) that many oversized lists: serial replay (a rank of many cannot decide that alone)
     if (c[0]) {                                                           // lists beyond the LDS kernel: same marking out of global scratch, one wavefront each
         const u32 nhv = (u32)c[0];
         WS(hsize, u32, WS_RA_HSIZE, nhv); WS(hscr, u64, WS_RA_HSCR, nhv);
@@ -1192,7 +1239,7 @@ int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved
         if (e2 != hipSuccess) { err = std::string("k_ra_mark_big: ") + hipGetErrorString(e2); return SAGE2OV_ERR_DEVICE; }
         HIPCHK(hipMemcpy(c, d->d_counters + 8, sizeof c, hipMemcpyDeviceToHost));
     }
-    u64 nsv = 0; { int rc = scan_u32(d, svn, nun, svoff, &nsv, err); if (rc) return rc; }
+    u64 nsv = 0; if (nun) { int rc = scan_u32(d, svn, nun, svoff, &nsv, err); if (rc) return rc; }
     if (d->n_cand + nsv > d->cand_cap || getenv("SAGE2OV_TEST_SMALL_BUFFERS")) {
         EdgeCand* ncand = nullptr; const u64 ncap = d->n_cand + nsv + 1024;
         HIPCHK(hipMalloc(&ncand, ncap * sizeof(EdgeCand)));
@@ -1200,12 +1247,13 @@ int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved
         hipFree(d->cand); d->cand = ncand; d->cand_cap = ncap;
     }
     lap("final lists + marks");
-    hipLaunchKernelGGL(k_ra_emit, dim3(gb), dim3(256), 0, d->stream, ids, (u64)nun, offs, deg, ent, rm, svoff, d->cand, (u64)d->n_cand, (u64)d->cand_cap);
+    if (nun) hipLaunchKernelGGL(k_ra_emit, dim3(gb), dim3(256), 0, d->stream, ids, (u64)nun, offs, deg, ent, rm, svoff, d->cand, (u64)d->n_cand, (u64)d->cand_cap);
     HIPCHK(hipGetLastError());
     d->n_cand += nsv;
     *inserted = ranked ? 2 * present : nh; *removed = c[1]; *done = 1;
     HIPCHK(hipEventRecord(d->ev[1], d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
     float ms = 0; hipEventElapsedTime(&ms, d->ev[0], d->ev[1]); d->tm.hits_ms += ms;
+    hipEventElapsedTime(&ms, d->ev[5], d->ev[1]); d->tm.marks_ms += ms;
     return 0;
 }
 

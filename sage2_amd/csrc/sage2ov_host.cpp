@@ -81,6 +81,8 @@ struct sage2ov_ctx {
     std::vector<FinalEdge> edges; bool edgesOnHost = false;
     SimplifiedGraph g4; bool g4Valid = false;
     double reduce_ms = 0, total_ms = 0;
+    // multi-rank contexts: the survivors this rank's share of the reduce phase re-emitted = candidates [survBase, survBase + survCount) of the device list
+    uint64_t survBase = 0, survCount = 0, removedPartial = 0; bool survivorsExchanged = true;
 
     int fail(int code, const std::string& m) { err = m; return code; }
 };
@@ -912,10 +914,13 @@ int sage2ov_overlap_reduce(sage2ov_ctx* c) {
         const char* ev = getenv("SAGE2OV_DEVICE_REDUCE_MIN");
         const uint64_t minUn = ev ? strtoull(ev, nullptr, 10) : 4096;
         uint64_t nun0 = 0, nh0 = 0, ins = 0, rem = 0; int done = 0;
+        const bool multi = c->cfg.world > 1;
+        c->survBase = dev_cand_count(c->dev); c->survCount = 0; c->removedPartial = 0; c->survivorsExchanged = !multi;
         if (!getenv("SAGE2OV_HOST_REDUCE")) {
-            int rc0 = dev_reduce_device(c->dev, minUn, &nun0, &nh0, &ins, &rem, &done, c->err); if (rc0) return rc0;
+            int rc0 = dev_reduce_device(c->dev, minUn, &nun0, &nh0, &ins, &rem, &done, c->err, c->cfg.rank, multi ? c->cfg.world : 1); if (rc0) return rc0;
         }
         if (done) {
+            c->survCount = dev_cand_count(c->dev) - c->survBase; c->removedPartial = rem;
             c->ostats.unresolved_hits = nh0; c->ostats.edges_inserted = ins; c->ostats.transitive_removed = rem;
             c->reduce_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             c->reduced = true; c->converted = false; return SAGE2OV_OK;
@@ -955,7 +960,10 @@ int sage2ov_overlap_reduce(sage2ov_ctx* c) {
         // surviving list entries of unresolved reads with to > from replace what the device dropped
         std::vector<EdgeCand> survivors;
         for (uint32_t i : ids) for (auto& e : R.adj[R.dense[i] - 1]) if (e.to > i) survivors.push_back(EdgeCand{i, e.to, e.len, e.type});
+        // (multi-rank contexts: the replay is replicated -- every rank computes the same survivors; rank 0's are the ones that are exchanged)
+        if (c->cfg.world > 1 && c->cfg.rank != 0) { survivors.clear(); c->removedPartial = 0; } else c->removedPartial = R.removed;
         rc = dev_append_edges(c->dev, survivors.data(), survivors.size(), c->err); if (rc) return rc;
+        c->survCount = survivors.size();
         lap("survivors -> device");
     }
     c->reduce_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -974,8 +982,25 @@ int sage2ov_debug_all_hits(sage2ov_ctx* c, uint32_t* out, uint64_t cap_rows, uin
         for (size_t x = 0; x < hits.size(); x++) { out[5 * x] = hits[x].from; out[5 * x + 1] = hits[x].to; out[5 * x + 2] = hits[x].type; out[5 * x + 3] = (uint32_t)hits[x].len; out[5 * x + 4] = hits[x].seq; } }
     return SAGE2OV_OK;
 }
+// ---- sharded reduce phase: survivor buckets (multi-rank contexts)
+int sage2ov_shard_survivors_count(const sage2ov_ctx* c, uint64_t* n, uint64_t* removed_partial) {
+    if (!c || !n || !c->reduced) return SAGE2OV_ERR_ARG;
+    *n = c->survCount; if (removed_partial) *removed_partial = c->removedPartial; return SAGE2OV_OK;
+}
+int sage2ov_shard_survivors_export(sage2ov_ctx* c, void* dst, uint64_t cap) {
+    if (!c || (!dst && c->survCount)) return SAGE2OV_ERR_ARG; if (!c->reduced) return c->fail(SAGE2OV_ERR_ARG, "run the reduce phase first");
+    if (c->survCount > cap) return c->fail(SAGE2OV_ERR_ARG, "destination too small");
+    return dev_export_cand_range(c->dev, dst, c->survBase, c->survCount, c->err);
+}
+int sage2ov_shard_survivors_set(sage2ov_ctx* c, const void* src, uint64_t n_total, uint64_t removed_total) {
+    if (!c || (!src && n_total)) return SAGE2OV_ERR_ARG; if (!c->reduced) return c->fail(SAGE2OV_ERR_ARG, "run the reduce phase first");
+    int rc = dev_replace_cand_tail(c->dev, c->survBase, src, n_total, c->err); if (rc) return rc;
+    c->survCount = n_total; c->removedPartial = removed_total; c->ostats.transitive_removed = removed_total; c->survivorsExchanged = true; c->converted = false;
+    return SAGE2OV_OK;
+}
 int sage2ov_overlap_convert(sage2ov_ctx* c) {
     if (!c) return SAGE2OV_ERR_ARG; if (!c->reduced) return c->fail(SAGE2OV_ERR_ARG, "run the reduce phase first");
+    if (!c->survivorsExchanged) return c->fail(SAGE2OV_ERR_ARG, "multi-rank context: exchange the survivor buckets of the reduce phase first (sage2ov_shard_survivors_*)");
     uint64_t nf = 0; int rc = dev_convert(c->dev, &nf, c->err); if (rc) return rc;
     c->ostats.edges = nf; c->edgesOnHost = false; c->converted = true; return SAGE2OV_OK;
 }
@@ -1131,6 +1156,7 @@ int sage2ov_timings_get(const sage2ov_ctx* c, sage2ov_timings* o) {
     DevTimings t; if (c->dev) dev_timings(c->dev, &t);
     o->index_ms = t.index_ms; o->probe_ms = t.probe_ms; o->reciprocal_ms = t.reciprocal_ms; o->reduce_ms = c->reduce_ms; o->convert_ms = t.convert_ms;
     o->total_ms = c->total_ms; o->probe_kernel_ms = t.probe_kernel_ms; o->probe_kernel_launches = t.probe_launches; o->sequential_reads = t.slow_reads; o->organize_ms = t.organize_ms; o->probe_fast_launches = t.probe_fast_launches;
+    o->reciprocal_cond_ms = t.recip_cond_ms; o->reduce_marks_ms = t.marks_ms;
     return SAGE2OV_OK;
 }
 

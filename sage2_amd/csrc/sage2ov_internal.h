@@ -31,7 +31,7 @@ struct EdgeCand { uint32_t from, to; uint32_t len; uint32_t type; };   // from <
 struct Hit { uint32_t from; uint32_t to; int32_t len; uint16_t seq_hi; uint8_t type; uint8_t pad; uint32_t seq; };
 struct FinalEdge { uint32_t from, to, len, len_twin; uint32_t type; };
 
-struct DevTimings { double index_ms = 0, probe_ms = 0, reciprocal_ms = 0, hits_ms = 0, convert_ms = 0, probe_kernel_ms = 0, organize_ms = 0; uint64_t probe_launches = 0, slow_reads = 0, probe_fast_launches = 0; };
+struct DevTimings { double index_ms = 0, probe_ms = 0, reciprocal_ms = 0, hits_ms = 0, convert_ms = 0, probe_kernel_ms = 0, organize_ms = 0, recip_cond_ms = 0, marks_ms = 0; uint64_t probe_launches = 0, slow_reads = 0, probe_fast_launches = 0; };
 
 struct Device;   // opaque, lives in sage2ov_device.hip
 
@@ -67,7 +67,10 @@ int dev_collect_reduce_edges(Device* d, std::vector<EdgeCand>& out, std::string&
 struct OrgAscii { const char* bases; uint64_t nbytes; const uint64_t* off; uint64_t n_in; uint64_t good = 0, total_bp = 0, small = 0; int maxL = 0, minL = 0, S = 0; };
 int dev_organize_reads(Device* d, const uint64_t* pool, uint64_t pool_words, const uint64_t* off, const uint16_t* len, uint64_t n, int S, int minL, int maxL, int k,
                        uint64_t* N_out, std::vector<uint64_t>& words_out, std::vector<uint16_t>& freq_out, std::string& err, OrgAscii* ascii = nullptr);
-int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved, uint64_t* n_hits, uint64_t* inserted, uint64_t* removed, int* done, std::string& err);
+int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved, uint64_t* n_hits, uint64_t* inserted, uint64_t* removed, int* done, std::string& err,
+                      uint32_t shareRank = 0, uint32_t shareWorld = 1);
+int dev_export_cand_range(Device* d, void* dev_dst, uint64_t first, uint64_t n, std::string& err);
+int dev_replace_cand_tail(Device* d, uint64_t keep, const void* dev_src, uint64_t n, std::string& err);
 // append host-computed edge candidates (from the reduce replay) to the device candidate list
 int dev_debug_table(Device* d, uint64_t* out5, std::string& err);
 int dev_debug_keys(Device* d, uint64_t* out, std::string& err);

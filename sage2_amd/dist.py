@@ -6,7 +6,8 @@ range-partitioned for the probe/verify kernel.  Exchange steps -- al
      the reciprocal test reads the NEIGHBOUR's record (economyGraph.cpp:460);
   2. MAX all-reduce (= OR) of the two containment bit planes: a containment mark (economyGraph.cpp:735)
      lands on a read of any rank;
-  3. all-gather of the variable-size per-rank edge buckets (counts first, then max-padded buffers).
+  3. all-gather of the variable-size per-rank edge buckets (counts first, then max-padded buffers);
+  4. after the reduce phase (its marks are sharded over the ranks): all-gather of the per-rank survivor buckets, SUM of the removal counters.
 
 The tensor plumbing below is backend-agnostic (it is what the gloo tests exercise); `run_steps23_sharded`
 binds it to a sage2_amd.Context.
@@ -122,5 +123,20 @@ def run_steps23_sharded(ctx, device, group=None):
     allb = allb.contiguous()
     _sync(allb)
     ctx.shard_edges_set(allb.data_ptr() if total else 0, total)
+    # reduce phase: hit lists and adjacency of all unresolved reads on every rank, the marks (economyGraph.cpp:643-707) for this rank's share only;
+    # the surviving edges of the shares are exchanged like the edge buckets, the removal counters summed
     ctx.overlap_reduce()
+    ns, rem = ctx.shard_survivors_count()
+    sb = torch.zeros(max(ns, 1) * EDGE_BYTES, dtype=torch.uint8, device=device)
+    _sync(sb)
+    ctx.shard_survivors_export(sb.data_ptr(), max(ns, 1))
+    alls, stotal = allgather_edge_buckets(sb, ns, group)
+    remt = torch.tensor([rem], dtype=torch.int64, device=device)
+    if remt.is_cuda and _staged(group):
+        h = remt.cpu(); dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group); remt = h
+    else:
+        dist.all_reduce(remt, op=dist.ReduceOp.SUM, group=group)
+    alls = alls.contiguous()
+    _sync(alls)
+    ctx.shard_survivors_set(alls.data_ptr() if stotal else 0, stotal, int(remt.item()))
     ctx.overlap_convert()

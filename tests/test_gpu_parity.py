@@ -215,8 +215,11 @@ class _Hip:
         self.bufs = []
 
 
-@pytest.mark.parametrize("name,world", [("g2_clean150_k40", 2), ("g5_mixedlen_k21", 3), ("g3_noisy_rep_k21", 2), ("g4_highcopy_k21", 2)])
-def test_sharded_contexts_on_one_gpu_match_reference(name, world, tmp_path):
+@pytest.mark.parametrize("name,world,device_reduce", [("g2_clean150_k40", 2, False), ("g5_mixedlen_k21", 3, False), ("g3_noisy_rep_k21", 2, False), ("g4_highcopy_k21", 2, False),
+                                                      ("g3_noisy_rep_k21", 3, True), ("g4_highcopy_k21", 3, True), ("g9_repeats160k_k40", 2, True), ("g5_mixedlen_k21", 2, True)])
+def test_sharded_contexts_on_one_gpu_match_reference(name, world, device_reduce, tmp_path, monkeypatch):
+    if device_reduce:                                                  # the device forms of the reduce phase (symmetric / ranked), their marks sharded over the ranks
+        monkeypatch.setenv("SAGE2OV_DEVICE_REDUCE_MIN", "1")
     """The multi-GPU path without a cluster (SURVEY section 4): `world` rank contexts on ONE GPU, the collectives
     replaced by explicit concatenation / element-wise max of the very buffers the C ABI exports and imports.
     Every rank must end with the reference's P.graph3."""
@@ -250,12 +253,24 @@ def test_sharded_contexts_on_one_gpu_match_reference(name, world, tmp_path):
         p = hip.alloc(max(ne, 1) * EDGE_BYTES); c.shard_edges_export(p, max(ne, 1)); parts.append(hip.to_host(p, ne * EDGE_BYTES))
     allb = np.concatenate(parts); total = allb.size // EDGE_BYTES
     dall = hip.to_dev(allb)
-    want = fx.golden_graph3(name)
-    for r, c in enumerate(ctxs):
+    # reduce phase: every rank marks its share of the unresolved reads; the survivor buckets are concatenated, the removal counters summed
+    sparts, removed = [], 0
+    for c in ctxs:
         c.shard_edges_set(dall if total else 0, total)
-        c.overlap_reduce(); c.overlap_convert()
+        c.overlap_reduce()
+        ns, rem = c.shard_survivors_count(); removed += rem
+        p = hip.alloc(max(ns, 1) * EDGE_BYTES); c.shard_survivors_export(p, max(ns, 1)); sparts.append(hip.to_host(p, ns * EDGE_BYTES))
+    with pytest.raises(s2.Sage2ovError):
+        ctxs[0].overlap_convert()                                      # a multi-rank context refuses to convert before the exchange
+    alls = np.concatenate(sparts); stotal = alls.size // EDGE_BYTES
+    dsurv = hip.to_dev(alls)
+    if "transitive_removed" in m["counters"]:
+        assert removed == m["counters"]["transitive_removed"]
+    for r, c in enumerate(ctxs):
+        c.shard_survivors_set(dsurv if stotal else 0, stotal, removed)
+        c.overlap_convert()
         gp = str(tmp_path / f"r{r}.graph3"); c.graph_save(gp)
-        assert open(gp, "rb").read() == want, f"rank {r} differs from the reference"
+        assert fx.graph3_matches(gp, name), f"rank {r} differs from the reference"
         st = c.overlap_stats()
         assert st.contained_extension == m["counters"]["contained_extension"] and st.contained_size == m["counters"]["contained_size"]
     for c in ctxs:
