@@ -45,6 +45,38 @@ def algorithmic_bytes(n_unique, n_ov, n_edges, L, k):
     return total, probe
 
 
+XGMI_LINK_GBS = 153.0          # MI355X_MICROARCH.md / task notes: 7 xGMI links x ~153 GB/s per GPU (both directions of a link together)
+
+
+def scaling_model(n_unique, n_edges, ms1, ph, alt=None):
+    """MODEL, UNMEASURED: the step time on G ranks predicted from the ONE-GPU phase times of this run (no multi-GPU hardware is available to the
+    builder; the driver's scaling runs are the measurement).  Per rank: replicated = index build (without the minimiser groups once a rank probes
+    fewer than 24 M reads: dev_build_index) + cond half of the reciprocal pass + hit lists / adjacency of the reduce phase + convert; sharded = probe pass,
+    emit half of the reciprocal pass, marks of the reduce phase; exchanges = records (24 B/read), containment planes (2 B/read, all-reduce), edge
+    and survivor buckets (16 B/edge), each rank receiving (G-1)/G of the bytes over G-1 links at `link_efficiency` of one direction of a link,
+    plus a fixed latency per collective.  ph: phases of the one-GPU step (ms); alt: index / probe times measured without minimiser groups."""
+    eff, lat_ms, ncoll = 0.7, 0.05, 8
+    out = {"label": "model, unmeasured", "assumptions": {"xgmi_link_GBs": XGMI_LINK_GBS, "link_efficiency": eff, "receive_GBs_per_peer": XGMI_LINK_GBS / 2 * eff,
+                                                         "collectives_per_step": ncoll, "latency_ms_per_collective": lat_ms,
+                                                         "replicated": "index build, cond half of the reciprocal pass, hit lists + adjacency of the reduce phase, convert",
+                                                         "sharded": "probe pass, emit half of the reciprocal pass, marks of the reduce phase"},
+           "one_gpu_ms": ms1, "ranks": {}}
+    for G in (2, 4, 8):
+        groups = n_unique / G >= 24e6
+        index = ph["index_ms"] if (groups or not alt) else alt["index_ms"]
+        probe = (ph["probe_ms"] if (groups or not alt) else alt["probe_ms"]) / G
+        cond = ph.get("reciprocal_cond_ms", ph["reciprocal_ms"])
+        recip = cond + (ph["reciprocal_ms"] - cond) / G
+        marks = ph.get("reduce_marks_ms", 0.0)
+        reduce_ = (ph["reduce_ms"] - marks) + marks / G
+        bytes_recv = (24.0 * n_unique + 2 * 2.0 * n_unique + 16.0 * n_edges) * (G - 1) / G
+        exch = bytes_recv / ((G - 1) * XGMI_LINK_GBS / 2 * eff * 1e9) * 1e3 + ncoll * lat_ms
+        t = index + probe + recip + reduce_ + ph["convert_ms"] + exch
+        out["ranks"][str(G)] = {"ms": t, "speedup": ms1 / t, "index_ms": index, "probe_ms": probe, "reciprocal_ms": recip, "reduce_ms": reduce_, "convert_ms": ph["convert_ms"],
+                                "exchange_ms": exch, "minimiser_groups": bool(groups)}
+    return out
+
+
 def cpu_baseline(args, s2, fx):
     """Time the REFERENCE (oracle/_ref/libsage2ref_driver.so: the reference's own classes, built from
     /root/reference by oracle/Makefile) on a bounded sample of the same workload, and diff its P.graph3
@@ -283,7 +315,7 @@ def main():
         step()
     fence()
     t1 = time.perf_counter()
-    phase = dict(index_ms=0.0, probe_ms=0.0, reciprocal_ms=0.0, reduce_ms=0.0, convert_ms=0.0)
+    phase = dict(index_ms=0.0, probe_ms=0.0, reciprocal_ms=0.0, reduce_ms=0.0, convert_ms=0.0, reciprocal_cond_ms=0.0, reduce_marks_ms=0.0)
     pk_ms, pk_n, pk_f = 0.0, 0, 0
     for _ in range(args.steps):
         step()
@@ -378,6 +410,25 @@ def main():
             t4 = time.perf_counter(); c.graph_simplify(); w4 = time.perf_counter() - t4; s4 = c.simplify_stats()     # (the second call first frees the first one's result)
             return {"device_ms": s4.device_ms, "wall_ms_first_call": 1e3 * w41, "wall_ms": 1e3 * w4, "nodes_contracted": s4.nodes_contracted, "removed": s4.removed, "loop_iterations": s4.loop_iterations,
                     "edges_left": s4.edges, "reads_on_edges": s4.reads_on_edges}
+        if world == 1 and not sharded:
+            # what a rank of a multi-GPU run would do differently: no minimiser groups once it probes fewer than 24 M reads -- measured here (one untimed
+            # build + probe pass with the groups switched off), then the model
+            alt = None
+            if st.unique_reads >= 24e6 and args.err_ppm == 0:
+                saved = os.environ.get("SAGE2OV_MINIMIZER_INDEX")
+                os.environ["SAGE2OV_MINIMIZER_INDEX"] = "0"
+                try:
+                    ctx.timings_reset(); ctx.index_build(); ctx.overlap_probe_shard(); ta = ctx.timings()
+                    alt = {"index_ms": ta.index_ms, "probe_ms": ta.probe_ms}
+                finally:
+                    if saved is None:
+                        os.environ.pop("SAGE2OV_MINIMIZER_INDEX", None)
+                    else:
+                        os.environ["SAGE2OV_MINIMIZER_INDEX"] = saved
+                ctx.run_steps23()                                    # (back to the state the step-4 figures below start from)
+            res["scaling_model"] = scaling_model(st.unique_reads, ost.edges, ms_per_step, res["phases_ms"], alt)
+            if alt:
+                res["scaling_model"]["without_minimiser_groups_ms"] = alt
         if world == 1 and not args.no_step4:
             res["step4"] = step4_of(ctx)
         def side_workload(spd, nsteps, with_step4=False):
@@ -387,7 +438,7 @@ def main():
             c = s2.Context(args.k, device=local)
             c.reads_add_synth(sp, s2.synth_genome(sp)); c.reads_organize()
             c.run_steps23(); torch.cuda.synchronize()
-            t_ = time.perf_counter(); ph = dict(index_ms=0.0, probe_ms=0.0, reciprocal_ms=0.0, reduce_ms=0.0, convert_ms=0.0); pkm, pkn = 0.0, 0
+            t_ = time.perf_counter(); ph = dict(index_ms=0.0, probe_ms=0.0, reciprocal_ms=0.0, reduce_ms=0.0, convert_ms=0.0, reciprocal_cond_ms=0.0, reduce_marks_ms=0.0); pkm, pkn = 0.0, 0
             for _ in range(nsteps):
                 c.run_steps23(); tm_ = c.timings()
                 for kph in ph:
@@ -408,6 +459,7 @@ def main():
                    "verified_overlaps": o_.verified_overlaps, "edges": o_.edges, "edges_crc32": crc_, "unresolved_reads": o_.left_to_explore, "long_buckets": c.index_stats().long_buckets,
                    "oracle_digest_asserted": dn_, "phases_ms": {kph: v / nsteps for kph, v in ph.items()},
                    "probe_kernel_ms": pkm / max(pkn, 1), "probe_kernel_algorithmic_frac": (a_pr / (pkm / max(pkn, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS) if pkm > 0 else None}
+            out["scaling_model"] = scaling_model(st_.unique_reads, o_.edges, 1e3 * per, out["phases_ms"])
             if with_step4 and not args.no_step4:
                 out["step4"] = step4_of(c)
             c.close()

@@ -1038,8 +1038,8 @@ int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved
     {
         { int rc = refresh_status_by_pos(d, err); if (rc) return rc; }
         const u32* order = d->idOf + 1;                                            // ids in locality order (positions 1..N)
-        if (ranked) {
-            locDev = d->posOf;
+        if (ranked) locDev = d->posOf;
+        if (ranked || shareWorld > 1) {                                            // (several ranks cut the SAME list into shares: it must not depend on the order of atomics)
             // the unresolved reads listed in LOCALITY order (a stable compaction of `order`): their potential lists are then laid out in that
             // order too, so the lists the host's walk visits one after the other sit next to each other in memory (cache lines, TLB)
             WS(flg, u32, WS_RR_IN, N + 2); WS(fpos, u32, WS_RR_WIDX, N + 2);

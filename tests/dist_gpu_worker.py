@@ -32,9 +32,14 @@ def main():
     for _ in range(2):                       # twice: the second pass starts from the state the first one left
         run_steps23_sharded(ctx, dev)
     gp = os.path.join(out, f"r{rank}.graph3"); ctx.graph_save(gp)
-    ok = open(gp, "rb").read() == fx.golden_graph3(name)
+    same = open(gp, "rb").read() == fx.golden_graph3(name)
     st = ctx.overlap_stats()
-    ok = ok and st.contained_extension == m["counters"]["contained_extension"] and st.contained_size == m["counters"]["contained_size"]
+    ok = same and st.contained_extension == m["counters"]["contained_extension"] and st.contained_size == m["counters"]["contained_size"]
+    if "transitive_removed" in m["counters"]:
+        ok = ok and st.transitive_removed == m["counters"]["transitive_removed"]          # (summed over the ranks' shares of the reduce phase)
+    if not ok:
+        print(f"rank {rank}: graph3 identical {same}; contained {st.contained_extension}/{m['counters']['contained_extension']} {st.contained_size}/{m['counters']['contained_size']}; "
+              f"edges {st.edges}; removed {st.transitive_removed}/{m['counters'].get('transitive_removed')}", flush=True)
     t = torch.tensor([1 if ok else 0], device=dev if backend == "nccl" else "cpu"); dist.all_reduce(t, op=dist.ReduceOp.MIN)
     if rank == 0:
         print("DIST_GPU_OK" if int(t.item()) == 1 else "DIST_GPU_MISMATCH", world, dist.get_backend(), flush=True)
