@@ -175,6 +175,10 @@ int sage2ov_graph4_save(sage2ov_ctx* ctx, const char* path);
 
 /* diagnostic: table census {occupied, inline, claimed-but-unfilled, zero-tag, entries in short CSR buckets} */
 int sage2ov_debug_table(sage2ov_ctx* ctx, uint64_t* out5);
+/* diagnostic: device memory {free now, total, LOWEST free seen at the library's sampling points since the context was created (end of step 1, the index
+ * build's peak, end of the probe pass, reduce, convert), bytes held by the context's grow-only workspace arena}: the high-water mark of a run is
+ * total - out[2] when the context is the only user of the GPU */
+int sage2ov_debug_meminfo(sage2ov_ctx* ctx, uint64_t* out4);
 /* diagnostic: the four index keys (hashTable.cpp:96-104) of every read as the device computes them: 8N u64 (hi,lo per entry) */
 int sage2ov_debug_keys(sage2ov_ctx* ctx, uint64_t* out);
 /* diagnostic: the directional hit list (economyGraph.cpp:591-633: to, edge type, length) of EVERY read, rows of

@@ -298,6 +298,12 @@ class Context:
     def stream(self):
         return lib().sage2ov_stream(self._h)
 
+    def debug_meminfo(self):
+        """{free, total, lowest free seen by the library, workspace arena bytes} of the context's GPU"""
+        o = (C.c_uint64 * 4)()
+        self._chk(lib().sage2ov_debug_meminfo(self._h, o))
+        return dict(free=o[0], total=o[1], lowest_free=o[2], arena=o[3])
+
     # ---- multi-GPU exchange points
     def shard_range(self):
         lo, hi = C.c_uint64(), C.c_uint64()

@@ -64,6 +64,12 @@ struct Device {
     // final edges (device resident)
     FinalEdge* final_edges = nullptr; u64 n_final = 0;
     DevTimings tm;
+    u64 memLow = ~0ull;          // lowest free device memory seen at the sampling points (mem_sample)
+    // Memory-diet mode (round 3, BASELINE configs[4]: a billion reads per GPU): transient buffers are released at the end of their phase instead of kept for
+    // the next step, the id-ordered read store is released once the locality-ordered one exists (uniform read length only; rebuilt for the next index
+    // build), no minimiser groups, the per-read result arrays and the candidate list are allocated when they are first needed.  On when the whole
+    // footprint of the default mode (~640 bytes per read) would pass 70 % of the device's memory, or SAGE2OV_MEMORY_DIET=1 (0 forbids it).
+    bool diet = false;
     // hits written out by the initial pass (k_probe_fast<..., TAIL = 2> on noisy data, one context probing everything): the reduce phase filters them
     struct PreHits { bool valid = false; Hit* hits = nullptr; u64 cap = 0, used = 0; u64* base = nullptr; } pre;
     void* s4keep = nullptr;      // step 4: the simplified graph stays in HBM until the next call (S4Keep)
@@ -82,6 +88,13 @@ static void* ws_get(Device* d, int id, size_t bytes) {
     }
     return b.p;
 }
+static void ws_free(Device* d, int id) { Device::Buf& b = d->ws[id]; if (b.p) hipFree(b.p); b.p = nullptr; b.cap = 0; }
+static void decide_diet(Device* d) {
+    size_t fr = 0, to = 0; d->diet = false;
+    if (hipMemGetInfo(&fr, &to) == hipSuccess && to) d->diet = (double)(d->N + 1) * 640.0 > 0.7 * (double)to;
+    if (const char* ev = getenv("SAGE2OV_MEMORY_DIET")) d->diet = atoi(ev) != 0;
+}
+static void mem_sample(Device* d) { size_t fr = 0, to = 0; if (hipMemGetInfo(&fr, &to) == hipSuccess) d->memLow = std::min<u64>(d->memLow, (u64)fr); }
 #define WS(var, type, id, count)                                                                     \
     type* var = (type*)ws_get(d, id, (size_t)(count) * sizeof(type));                                \
     if (!var) { err = std::string("workspace allocation failed: ") + #id; return SAGE2OV_ERR_NOMEM; }
@@ -132,6 +145,7 @@ static void free_reads(Device* d) {
     hipFree(d->reads); hipFree(d->right); hipFree(d->left); hipFree(d->conn); hipFree(d->cflag);
     hipFree(d->status); hipFree(d->cand);     // slots / csr / final_edges live in the workspace arena
     for (auto& b : d->ws) { if (b.p) hipFree(b.p); b.p = nullptr; b.cap = 0; }
+    d->readsLoc = nullptr; d->idOf = d->posOf = nullptr; d->statusP = nullptr; d->metaP = nullptr; d->mi1 = d->krec = nullptr; d->cand_cap = 0; d->n_cand = 0;
     d->reads = d->slots = nullptr; d->csr = nullptr; d->right = d->left = nullptr; d->conn = d->cflag = nullptr; d->status = nullptr; d->cand = nullptr; d->final_edges = nullptr;
 }
 void dev_destroy(Device* d) {
@@ -149,6 +163,14 @@ int dev_sync(Device* d, std::string& err) { HIPCHK(hipStreamSynchronize(d->strea
 void dev_timings(Device* d, DevTimings* t) { *t = d->tm; }
 void dev_reset_timings(Device* d) { d->tm = DevTimings(); }
 
+// per-read results + candidate list: allocated when the probe pass first needs them (after the index build's transients are gone in diet mode)
+static int ensure_results(Device* d, std::string& err) {
+    const u64 N = d->N;
+    if (!d->right) { HIPCHK(hipMalloc(&d->right, (N + 1) * sizeof(u64))); HIPCHK(hipMalloc(&d->left, (N + 1) * sizeof(u64)));
+                     HIPCHK(hipMalloc(&d->conn, (N + 1) * sizeof(u32))); HIPCHK(hipMalloc(&d->cflag, (N + 1) * sizeof(u32))); HIPCHK(hipMalloc(&d->status, (N + 1))); }
+    if (!d->cand && !d->diet) { d->cand_cap = 2 * N + 1024; HIPCHK(hipMalloc(&d->cand, d->cand_cap * sizeof(EdgeCand))); }      // (diet: sized by a counting pass of the reciprocal kernel)
+    return 0;
+}
 int dev_upload_reads(Device* d, const uint64_t* words, uint64_t N, int S, int minL, int maxL, int k, std::string& err) {
     HIPCHK(hipSetDevice(d->ordinal));
     if (S != 4 && S != 8 && S != 16 && S != 32) { err = "unsupported words-per-read (read length limit is 1018 bases)"; return SAGE2OV_ERR_LIMIT; }
@@ -157,18 +179,15 @@ int dev_upload_reads(Device* d, const uint64_t* words, uint64_t N, int S, int mi
     d->N = N; d->S = S; d->maxL = maxL; d->k = k; d->h = k > 64 ? 64 : k; d->uniL = (N && minL == maxL) ? maxL : 0;
     HIPCHK(hipMalloc(&d->reads, (N + 1) * S * sizeof(u64)));
     HIPCHK(hipMemcpyAsync(d->reads, words, (N + 1) * S * sizeof(u64), hipMemcpyHostToDevice, d->stream));
-    HIPCHK(hipMalloc(&d->right, (N + 1) * sizeof(u64))); HIPCHK(hipMalloc(&d->left, (N + 1) * sizeof(u64)));
-    HIPCHK(hipMalloc(&d->conn, (N + 1) * sizeof(u32))); HIPCHK(hipMalloc(&d->cflag, (N + 1) * sizeof(u32)));
-    HIPCHK(hipMalloc(&d->status, (N + 1)));
-    d->cand_cap = 2 * N + 1024;
-    HIPCHK(hipMalloc(&d->cand, d->cand_cap * sizeof(EdgeCand)));
     HIPCHK(hipStreamSynchronize(d->stream));
+    decide_diet(d);
+    if (!d->diet) { int rc = ensure_results(d, err); if (rc) return rc; }
     return 0;
 }
 
 static int scan_u32(Device* d, const u32* in, u64 n, u32* out, u64* total, std::string& err);
-struct PtBufs { u32* K[2]; u64* P[2]; u32* M[2]; };
-static int partition_by_window(Device* d, PtBufs& B, bool hasP, bool hasM, u32 n, int shiftW, u64 nWin, bool digit0Counted, u32* cnt, u32* base, u32* off, int* cur_out, std::string& err, bool keyFromP = false);
+struct PtBufs { u32* E[2]; int W; };      // two buffers of n tuples of W dwords each (kernels_partition.inc)
+static int partition_by_window(Device* d, PtBufs& B, int keyw, u32 n, int shiftW, u64 nWin, bool digit0Counted, u32* cnt, u32* base, u32* off, int* cur_out, std::string& err);
 // Step 1 on the device: see k_org_canon.  On return the read store is resident exactly as after dev_upload_reads, and the
 // host receives the image (for the .reads writer, lengths) and the frequencies.
 int dev_organize_reads(Device* d, const uint64_t* pool, uint64_t pool_words, const uint64_t* off, const uint16_t* len, uint64_t n, int S, int minL, int maxL, int k,
@@ -261,26 +280,26 @@ int dev_organize_reads(Device* d, const uint64_t* pool, uint64_t pool_words, con
     // the organised store becomes the context's read store (same state as after dev_upload_reads)
     free_reads(d);
     d->N = N; d->S = S; d->maxL = maxL; d->k = k; d->h = k > 64 ? 64 : k; d->reads = reads; d->uniL = (N && minL == maxL) ? maxL : 0;
-    HIPCHK(hipMalloc(&d->right, (N + 1) * sizeof(u64))); HIPCHK(hipMalloc(&d->left, (N + 1) * sizeof(u64)));
-    HIPCHK(hipMalloc(&d->conn, (N + 1) * sizeof(u32))); HIPCHK(hipMalloc(&d->cflag, (N + 1) * sizeof(u32)));
-    HIPCHK(hipMalloc(&d->status, (N + 1)));
-    d->cand_cap = 2 * N + 1024;
-    HIPCHK(hipMalloc(&d->cand, d->cand_cap * sizeof(EdgeCand)));
+    mem_sample(d);
+    // the organiser's work space (the staged reads, their slot image, the sort's key / value pairs: ~180 bytes per read) is not needed again
+    for (int id : {WS_ORG_POOL, WS_ORG_OFF, WS_ORG_LEN, WS_ORG_IMG, WS_ORG_K0, WS_ORG_K1, WS_ORG_V0, WS_ORG_V1, WS_ORG_HIST, WS_ORG_HSCAN, WS_ORG_FLAG, WS_ORG_UID, WS_ORG_HEAD, WS_ORG_GFLAG, WS_ORG_GPOS}) ws_free(d, id);
+    decide_diet(d);
+    if (!d->diet) { int rc = ensure_results(d, err); if (rc) return rc; }
     *N_out = N;
     return 0;
 }
 
-static int build_locality_order(Device* d, u64 lo, u64 hi, const u64** order_out, std::string& err);
+static int build_locality_order(Device* d, u64 lo, u64 hi, const u32** order_out, std::string& err);
 // The locality-ordered copy of the read store + the two translation tables (see Device::readsLoc).  Part of the index build (timed with it).
 // Round 3: two kernels.  k_loc_index writes the translation tables from the order; k_loc_scatter then STREAMS the id-ordered store (coalesced reads) and
 // writes every slot to its position (whole 32 / 64 / 128-byte slots: no read-modify-write at the memory side).  The gather it replaces pulled every
 // 64-byte slot as a 128-byte line request: 5.4 GB of reads for 2.7 GB of reads at configs[2].
-__global__ void k_loc_index(const u64* __restrict__ order, u64 N, u32* idOf, u32* posOf, unsigned short* meta) {
+__global__ void k_loc_index(const u32* __restrict__ order, u64 N, u32* idOf, u32* posOf, unsigned short* meta) {      // order: 3 dwords per position {hash, id, meta}
     const u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (p == 0) { idOf[0] = 0; posOf[0] = 0; idOf[N + 1] = 0; posOf[N + 1] = 0; meta[0] = 0xFFFF; meta[N + 1] = 0xFFFF; }
     if (p >= N) return;
-    const u64 o = order ? order[p] : (u64)(p + 1) | (0xFFFFull << 32); const u32 id = (u32)o;
-    idOf[p + 1] = id; posOf[id] = (u32)(p + 1); meta[p + 1] = (unsigned short)(o >> 32);       // meta 0xFFFF: no minimiser information (no window reuse)
+    const u32 id = order ? order[3 * p + 1] : (u32)(p + 1); const u32 mt = order ? order[3 * p + 2] : 0xFFFFu;
+    idOf[p + 1] = id; posOf[id] = (u32)(p + 1); meta[p + 1] = (unsigned short)mt;       // meta 0xFFFF: no minimiser information (no window reuse)
 }
 __global__ void k_loc_scatter(const u64* __restrict__ reads, const u32* __restrict__ posOf, u64 N, int S, u64* out) {
     const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;      // one 16-byte piece of a slot per thread
@@ -299,7 +318,7 @@ static int build_locality_store(Device* d, std::string& err) {
     WS(rl, u64, WS_LOC_READS, (N + 1) * d->S); WS(io, u32, WS_LOC_IDOF, N + 2); WS(po, u32, WS_LOC_POSOF, N + 2); WS(sp, uint8_t, WS_LOC_STATUS, N + 2);
     WS(me, unsigned short, WS_LOC_META, N + 2);
     d->readsLoc = rl; d->idOf = io; d->posOf = po; d->statusP = sp; d->metaP = me;
-    const u64* order = nullptr;
+    const u32* order = nullptr;
     if (N && !getenv("SAGE2OV_NO_LOCALITY")) { int rc = build_locality_order(d, 1, N + 1, &order, err); if (rc) return rc; }
     hipLaunchKernelGGL(k_loc_index, dim3(grid_for(std::max<u64>(N, 1), 256)), dim3(256), 0, d->stream, order, (u64)N, io, po, me);
     hipLaunchKernelGGL(k_loc_scatter, dim3(grid_for((N + 1) * (d->S / 2), 256)), dim3(256), 0, d->stream, d->reads, po, (u64)N, d->S, rl);
@@ -313,15 +332,13 @@ static int refresh_status_by_pos(Device* d, std::string& err) {
 // exclusive scan without the read-back of the total (no host synchronisation)
 static int scan_u32_async(Device* d, const u32* in, u64 n, u32* out, std::string& err);
 
-// LSD radix passes that sort the tuples (K, optional P / M) by the window id (K >> shiftW), window ids < nWin; `digit 0 counted`
-// tells that cnt already holds the first digit's per-tile histogram (taken by the kernel that wrote the tuples).  On return
-// *Ks / *Ps / *Ms point at the sorted arrays (one of the two buffer sets) and off[0..nWin] holds the window boundaries.
 static int pt_digits(u64 nWin, int* bits, int* nd) {            // window id bits, number of <= 9-bit digits
     int wb = 0; while ((1ull << wb) < nWin) wb++;
     *bits = wb; *nd = wb == 0 ? 0 : (wb + 8) / 9; return 0;
 }
-// keyFromP: the digits come from the HIGH WORD of P instead of K (K rides along); no window bounds in that form.
-static int partition_by_window(Device* d, PtBufs& B, bool hasP, bool hasM, u32 n, int shiftW, u64 nWin, bool digit0Counted, u32* cnt, u32* base, u32* off, int* cur_out, std::string& err, bool keyFromP) {
+// The tuples are sorted by the window id (dword keyw >> shiftW); `digit 0 counted` tells that cnt already holds the first digit's per-tile histogram (taken
+// by the kernel that wrote the tuples).  On return B.E[*cur_out] is the sorted array and off[0..nWin] (if given) holds the window boundaries.
+static int partition_by_window(Device* d, PtBufs& B, int keyw, u32 n, int shiftW, u64 nWin, bool digit0Counted, u32* cnt, u32* base, u32* off, int* cur_out, std::string& err) {
     int wb, nd; pt_digits(nWin, &wb, &nd);
     const u32 ntiles = (u32)((n + PT_TILE - 1) / PT_TILE);
     int cur = 0;
@@ -329,16 +346,16 @@ static int partition_by_window(Device* d, PtBufs& B, bool hasP, bool hasM, u32 n
         const int bper = nd ? (wb + nd - 1) / nd : 0;
         for (int j = 0; j < nd; j++) {
             const int shift = shiftW + j * bper; const int bj = std::min(bper, wb - j * bper); const u32 mask = (1u << bj) - 1u;
-            if (!(j == 0 && digit0Counted)) hipLaunchKernelGGL(k_pt_hist, dim3(ntiles), dim3(PT_THREADS), 0, d->stream, keyFromP ? (const u32*)B.P[cur] + 1 : B.K[cur], n, shift, mask, cnt, ntiles, keyFromP ? 2u : 1u);
+            if (!(j == 0 && digit0Counted)) hipLaunchKernelGGL(k_pt_hist, dim3(ntiles), dim3(PT_THREADS), 0, d->stream, B.E[cur] + keyw, n, shift, mask, cnt, ntiles, (u32)B.W);
             int rc = scan_u32_async(d, cnt, (u64)(mask + 1) * ntiles, base, err); if (rc) return rc;
             const int o = cur ^ 1;
-            if (keyFromP) hipLaunchKernelGGL((k_pt_scatter<true, false, true>), dim3(ntiles), dim3(PT_THREADS), 0, d->stream, B.K[cur], B.P[cur], (const u32*)nullptr, n, shift, mask, base, ntiles, B.K[o], B.P[o], (u32*)nullptr);
-            else if (hasP && hasM) hipLaunchKernelGGL((k_pt_scatter<true, true, false>), dim3(ntiles), dim3(PT_THREADS), 0, d->stream, B.K[cur], B.P[cur], B.M[cur], n, shift, mask, base, ntiles, B.K[o], B.P[o], B.M[o]);
-            else if (hasP) hipLaunchKernelGGL((k_pt_scatter<true, false, false>), dim3(ntiles), dim3(PT_THREADS), 0, d->stream, B.K[cur], B.P[cur], (const u32*)nullptr, n, shift, mask, base, ntiles, B.K[o], B.P[o], (u32*)nullptr);
-            else hipLaunchKernelGGL((k_pt_scatter<false, true, false>), dim3(ntiles), dim3(PT_THREADS), 0, d->stream, B.K[cur], (const u64*)nullptr, B.M[cur], n, shift, mask, base, ntiles, B.K[o], (u64*)nullptr, B.M[o]);
+            if (B.W == 4 && keyw == 0) hipLaunchKernelGGL((k_pt_scatter<4, 0>), dim3(ntiles), dim3(PT_THREADS), 0, d->stream, B.E[cur], n, shift, mask, base, ntiles, B.E[o]);
+            else if (B.W == 3 && keyw == 0) hipLaunchKernelGGL((k_pt_scatter<3, 0>), dim3(ntiles), dim3(PT_THREADS), 0, d->stream, B.E[cur], n, shift, mask, base, ntiles, B.E[o]);
+            else if (B.W == 3 && keyw == 2) hipLaunchKernelGGL((k_pt_scatter<3, 2>), dim3(ntiles), dim3(PT_THREADS), 0, d->stream, B.E[cur], n, shift, mask, base, ntiles, B.E[o]);
+            else { err = "partition: unsupported tuple format"; return SAGE2OV_ERR_INTERNAL; }
             cur = o;
         }
-        if (off && !keyFromP) hipLaunchKernelGGL(k_pt_bounds, dim3(grid_for(n, 256)), dim3(256), 0, d->stream, B.K[cur], n, shiftW, (u32)nWin, off);
+        if (off) hipLaunchKernelGGL(k_pt_bounds, dim3(grid_for(n, 256)), dim3(256), 0, d->stream, B.E[cur] + keyw, n, shiftW, (u32)nWin, off, (u32)B.W);
     } else if (off) HIPCHK(hipMemsetAsync(off, 0, (nWin + 1) * sizeof(u32), d->stream));
     HIPCHK(hipGetLastError());
     *cur_out = cur;
@@ -353,9 +370,13 @@ static void pt_first_digit(u64 nWin, int shiftW, int* shift0, u32* mask0, int* d
 
 int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t* csr_out, uint64_t* nlong_out, uint32_t* rebuilds, std::string& err) {
     HIPCHK(hipSetDevice(d->ordinal));
-    const u64 N = d->N; if (!d->reads) { err = "reads not resident"; return SAGE2OV_ERR_ARG; }
+    const u64 N = d->N; if (!d->reads && !d->readsLoc) { err = "reads not resident"; return SAGE2OV_ERR_ARG; }
     HIPCHK(hipEventRecord(d->ev[0], d->stream));                          // (the locality store is part of the build and of index_ms)
-    { int rc = build_locality_store(d, err); if (rc) return rc; }
+    if (d->reads) { int rc = build_locality_store(d, err); if (rc) return rc; }
+    // (diet mode, second and later builds: the id-ordered store was released after the first one; the locality-ordered store and its tables are what
+    //  this build would produce again -- the order is a function of the reads -- so they are kept)
+    if (d->diet && d->reads && d->uniL) { HIPCHK(hipStreamSynchronize(d->stream)); hipFree(d->reads); d->reads = nullptr; }      // every later reader takes lengths from uniL
+    const bool byPos = d->reads == nullptr;
     d->T = std::max<u64>(IX_W, (8 * N + IX_W - 1) / IX_W * IX_W);            // load <= 0.5, as hashTable.cpp:83 sizes it; whole windows
     // (tests: SAGE2OV_TEST_TABLE_SLOTS forces a larger table, e.g. beyond 2^32 slots -- slot indices are 64-bit, pair indices and window ids 32-bit)
     if (const char* ev = getenv("SAGE2OV_TEST_TABLE_SLOTS")) { const u64 want = strtoull(ev, nullptr, 10); if (want > d->T) d->T = (want + IX_W - 1) / IX_W * IX_W; }
@@ -369,17 +390,15 @@ int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t
     // since window reuse -- and pay when the uniform table is far beyond the caches: 11 ms of probe time against 7.6 ms of build time at
     // configs[2] on one GPU, nothing against 1.1 ms at configs[1], and 11 / world against 7.6 when the probe work is shared.  So they are
     // built for big read sets probed (mostly) by this context; SAGE2OV_MINIMIZER_INDEX=0/1 overrides (tests force 1 on small inputs).
-    bool wantMI = (double)N * d->probeShare >= 24e6;
+    bool wantMI = (double)N * d->probeShare >= 24e6 && !d->diet;
     if (const char* ev = getenv("SAGE2OV_MINIMIZER_INDEX")) wantMI = atoi(ev) != 0;
     if (getenv("SAGE2OV_NO_MINIMIZER_INDEX") || (d->h - std::min(d->h, 16) + 1) < 8) wantMI = false;
     u64 TL = 0; int tlBits = 0; u64 gW = 0;
     if (wantMI) { TL = IX_GW; tlBits = IX_GWLOG; while (TL < d->T / 4) { TL <<= 1; tlBits++; } gW = TL / IX_GW; }   // >= 2N group words
     const u64 nAlloc = std::max<u64>(4, (u64)n + 4);
     const u32 ntiles = (u32)((n + PT_TILE - 1) / PT_TILE);
-    PtBufs B;
-    { WS(a, u32, WS_PT_K0, nAlloc); B.K[0] = a; } { WS(a, u32, WS_PT_K1, nAlloc); B.K[1] = a; }
-    { WS(a, u64, WS_PT_P0, nAlloc); B.P[0] = a; } { WS(a, u64, WS_PT_P1, nAlloc); B.P[1] = a; }
-    { WS(a, u32, WS_PT_M0, nAlloc); B.M[0] = a; } { WS(a, u32, WS_PT_M1, nAlloc); B.M[1] = a; }
+    PtBufs B; B.W = wantMI ? 4 : 3;                                          // {K, M, entry, tag} with the groups, {K, entry, tag} without
+    { WS(a, u32, WS_PT_K0, nAlloc * B.W); B.E[0] = a; } { WS(a, u32, WS_PT_K1, nAlloc * B.W); B.E[1] = a; }
     WS(cnt, u32, WS_PT_CNT, (u64)PT_NB_MAX * std::max<u32>(ntiles, 1) + 2); WS(base, u32, WS_PT_BASE, (u64)PT_NB_MAX * std::max<u32>(ntiles, 1) + 2);
     WS(winOff, u32, WS_PT_OFF, nW + 2);
     u64* mi1 = nullptr; u64* krec = nullptr; u32* gOff = nullptr;
@@ -393,26 +412,28 @@ int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t
     auto lap = [&](const char* what) { if (!timing) return; hipStreamSynchronize(d->stream); auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[index] %-34s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - tp).count()); tp = t; };
     u64 c[9];
     for (int attempt = 0;; attempt++) {
-        HIPCHK(hipMemsetAsync(d->d_counters + 8, 0, 9 * sizeof(u64), d->stream));
+        HIPCHK(hipMemsetAsync(d->d_counters + 8, 0, 10 * sizeof(u64), d->stream));
         // ---- tuples of the 4N entries, sorted by the window of their home slot
         int shift0, doHist; u32 mask0; pt_first_digit(nW, IX_WPLOG, &shift0, &mask0, &doHist);
-        if (n) hipLaunchKernelGGL(k_ix_tuples, dim3(ntiles), dim3(PT_THREADS), 0, d->stream, d->reads, d->posOf, (u32)N, d->S, d->h, d->seed, (u32)(d->T >> 1), wantMI ? 1 : 0, shift0, mask0, doHist,
-                                  B.K[0], B.P[0], B.M[0], cnt, ntiles);
+        if (n) hipLaunchKernelGGL(k_ix_tuples, dim3(ntiles), dim3(PT_THREADS), 0, d->stream, byPos ? d->readsLoc : d->reads, d->posOf, byPos ? 1 : 0, (u32)N, d->S, d->h, d->seed, (u32)(d->T >> 1), wantMI ? 1 : 0, shift0, mask0, doHist,
+                                  B.E[0], cnt, ntiles);
         lap("tuples");
         int cur = 0;
-        { int rc = partition_by_window(d, B, true, wantMI, n, IX_WPLOG, nW, doHist != 0, cnt, base, winOff, &cur, err); if (rc) return rc; }
+        { int rc = partition_by_window(d, B, 0, n, IX_WPLOG, nW, doHist != 0, cnt, base, winOff, &cur, err); if (rc) return rc; }
         lap("partition by table window");
         // ---- the windows of the uniform table, built in LDS; group tuples into the free buffer set
-        IxWinArgs A; A.K = B.K[cur]; A.P = B.P[cur]; A.M = wantMI ? B.M[cur] : nullptr; A.winOff = winOff; A.nW = (u32)nW; A.slots = d->slots; A.csr = d->csr;
-        A.counters = d->d_counters + 8; A.big = big; A.big_cap = big_cap; A.idOf = d->idOf; A.gK = wantMI ? B.K[cur ^ 1] : nullptr; A.gP = wantMI ? B.P[cur ^ 1] : nullptr; A.wh = (u64*)B.P[cur ^ 1] ;
-        // (the scratch words of heavy windows and the group tuples share no buffer: tuples go to P[other] via gP, scratch needs its own)
-        { WS(whs, u64, WS_WHERE, nAlloc); A.wh = whs; }
+        IxWinArgs A; A.T = B.E[cur]; A.W = B.W; A.winOff = winOff; A.nW = (u32)nW; A.slots = d->slots; A.csr = d->csr;
+        A.counters = d->d_counters + 8; A.big = big; A.big_cap = big_cap; A.idOf = d->idOf; A.G = wantMI ? B.E[cur ^ 1] : nullptr; A.wh = nullptr;     // (group tuples, 12 bytes each, into the free 16-byte buffer)
+        // (the scratch words of heavy windows need a buffer of their own)
+        // one word per SURPLUS tuple of a heavy window (more than 3072 tuples where the mean is 2048: keys in thousands of reads); small inputs get the
+        // worst case (every tuple in one window), big ones an eighth of it
+        { const u64 whCap = n <= (64u << 20) ? nAlloc : nAlloc / 8; WS(whs, u64, WS_WHERE, whCap); A.wh = whs; A.wh_cap = whCap; }
         hipLaunchKernelGGL(k_ix_window, dim3((unsigned)std::min<u64>(nW, 256ull * 6)), dim3(256), 0, d->stream, A);      // persistent: two rounds of 3 workgroups per CU, each with ONE pair of statistics atomics
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(c, d->d_counters + 8, sizeof c, hipMemcpyDeviceToHost, d->stream));
         HIPCHK(hipStreamSynchronize(d->stream));
-        lap("table windows");
-        if (c[8]) { err = "index build: a key occurs in more than 1 M reads, or a table window overflowed"; return SAGE2OV_ERR_LIMIT; }
+        lap("table windows"); mem_sample(d);
+        if (c[8]) { err = "index build: a key occurs in more than 1 M reads, a table window overflowed, or the heavy windows' scratch ran out"; return SAGE2OV_ERR_LIMIT; }
         if (c[2] > big_cap) { err = "too many long buckets"; return SAGE2OV_ERR_LIMIT; }
         if (c[2]) {
             hipLaunchKernelGGL(k_index_purity, dim3(grid_for(c[2] * 64, 256)), dim3(256), 0, d->stream, d->readsLoc, d->S, d->h, big, c[2], d->csr, d->d_counters + 8);
@@ -424,18 +445,19 @@ int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t
             d->mi1 = nullptr; d->krec = nullptr; d->TL = 0; d->n_groups = 0;
             if (wantMI && d->n_keys > 0) {
                 const u32 nG = n;                                        // one group tuple per entry tuple position; those without a record (GT_INVALID) sort behind window gW - 1
-                PtBufs G; G.K[0] = B.K[cur ^ 1]; G.K[1] = B.K[cur]; G.P[0] = B.P[cur ^ 1]; G.P[1] = B.P[cur]; G.M[0] = G.M[1] = nullptr;   // (the entry tuples are no longer needed)
+                PtBufs G; G.W = 3; G.E[0] = B.E[cur ^ 1]; G.E[1] = B.E[cur];                                // (the entry tuples are no longer needed)
                 int gcur = 0; const int gshift = 31 - (tlBits - IX_GWLOG);                                  // keys are minimiser hashes >> 1
-                { int rc = partition_by_window(d, G, true, false, nG, gshift, gW + 1, false, cnt, base, gOff, &gcur, err); if (rc) return rc; }
+                { int rc = partition_by_window(d, G, 0, nG, gshift, gW + 1, false, cnt, base, gOff, &gcur, err); if (rc) return rc; }
                 lap("partition by group window");
-                MiWinArgs MA; MA.gK = G.K[gcur]; MA.gP = G.P[gcur]; MA.gOff = gOff; MA.gW = (u32)gW; MA.tlBits = tlBits; MA.mi1 = mi1; MA.krec = krec; MA.counters = d->d_counters + 8; MA.wh = A.wh;
+                MiWinArgs MA; MA.G = G.E[gcur]; MA.gOff = gOff; MA.gW = (u32)gW; MA.tlBits = tlBits; MA.mi1 = mi1; MA.krec = krec; MA.counters = d->d_counters + 8; MA.wh = A.wh; MA.wh_cap = A.wh_cap;
+                HIPCHK(hipMemsetAsync(d->d_counters + 8 + 9, 0, sizeof(u64), d->stream));                  // (the scratch cursor starts over)
                 hipLaunchKernelGGL(k_mi_window, dim3((unsigned)std::min<u64>(gW, 256ull * 8)), dim3(256), 0, d->stream, MA);
                 // the probe scan may run past the last group: empty records behind ALL records
                 u64 mc[3];
                 HIPCHK(hipMemcpyAsync(mc, d->d_counters + 8 + 5, sizeof mc, hipMemcpyDeviceToHost, d->stream));
                 HIPCHK(hipStreamSynchronize(d->stream));
                 HIPCHK(hipMemsetAsync(krec + mc[0], 0, MI_SCAN_PAD * sizeof(u64), d->stream));   // (mc[0] records, at krec[0 .. mc[0]))
-                lap("group windows");
+                lap("group windows"); mem_sample(d);
                 d->n_groups = mc[1];
                 if (getenv("SAGE2OV_VERIFY_MI")) {
                     u64* vo = nullptr; HIPCHK(hipMalloc(&vo, 2 * sizeof(u64))); HIPCHK(hipMemsetAsync(vo, 0, 2 * sizeof(u64), d->stream));
@@ -453,6 +475,7 @@ int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t
     HIPCHK(hipEventRecord(d->ev[1], d->stream));
     HIPCHK(hipStreamSynchronize(d->stream));
     float ms = 0; hipEventElapsedTime(&ms, d->ev[0], d->ev[1]); d->tm.index_ms += ms;
+    if (d->diet) for (int id : {WS_PT_K0, WS_PT_K1, WS_WHERE, WS_MINH, WS_OCUR, WS_PT_CNT, WS_PT_BASE, WS_PARTIAL, WS_PT_OFF}) ws_free(d, id);     // the sort's buffers: ~150 bytes per read
     *slots_out = d->T; *keys_out = d->n_keys; *csr_out = d->n_csr; *nlong_out = d->n_long;
     return 0;
 }
@@ -491,7 +514,7 @@ static int launch_probe(Device* d, ProbeArgs& A, std::string& err) {
 }
 static int scan_u32(Device* d, const u32* in, u64 n, u32* out, u64* total, std::string& err);
 // processing order of ids [lo,hi): grouped by the reads' global minimiser (see k_minimizer)
-static int build_locality_order(Device* d, u64 lo, u64 hi, const u64** order_out, std::string& err) {
+static int build_locality_order(Device* d, u64 lo, u64 hi, const u32** order_out, std::string& err) {
     const u64 n = hi - lo;
     // reads sorted by (top bits of their global minimiser's hash, strand of the minimiser, start of the read relative to it): LSD radix passes
     // (kernels_partition.inc), first the 9 bits of strand + offset, then 27 bits of the hash (three passes) -- reads with one minimiser end up next to each
@@ -500,19 +523,18 @@ static int build_locality_order(Device* d, u64 lo, u64 hi, const u64** order_out
     int lg = 27;
     if (const char* ev = getenv("SAGE2OV_ORDER_BITS")) lg = std::max(1, std::min(32, atoi(ev)));
     const u32 ntiles = (u32)((n + PT_TILE - 1) / PT_TILE);
-    PtBufs B; B.M[0] = B.M[1] = nullptr;
-    { WS(a, u32, WS_MINH, n + 4); B.K[0] = a; } { WS(a, u32, WS_OCUR, n + 4); B.K[1] = a; }
-    { WS(a, u64, WS_ORDER, n + 4); B.P[0] = a; } { WS(a, u64, WS_OOFF, n + 4); B.P[1] = a; }
+    PtBufs B; B.W = 3;                                                        // {hash, id, meta}
+    { WS(a, u32, WS_MINH, 3 * (n + 4)); B.E[0] = a; } { WS(a, u32, WS_OCUR, 3 * (n + 4)); B.E[1] = a; }
     WS(cnt, u32, WS_PT_CNT, (u64)PT_NB_MAX * std::max<u32>(ntiles, 1) + 2); WS(base, u32, WS_PT_BASE, (u64)PT_NB_MAX * std::max<u32>(ntiles, 1) + 2);
-    // K = the hash, P = meta << 32 | id, written by the minimiser kernel itself; pass 1 sorts by the meta (P's high word), passes 2-4 by the hash:
-    // one element format for all four passes (round 2 had a pack and a re-key kernel in between)
-    if (d->S == 4) hipLaunchKernelGGL((k_minimizer_t<4>), dim3(grid_for(n, 256)), dim3(256), 0, d->stream, d->reads, (u64)lo, (u64)hi, B.K[0], B.P[0]);
-    else if (d->S == 8) hipLaunchKernelGGL((k_minimizer_t<8>), dim3(grid_for(n, 256)), dim3(256), 0, d->stream, d->reads, (u64)lo, (u64)hi, B.K[0], B.P[0]);
-    else hipLaunchKernelGGL(k_minimizer, dim3(grid_for(n, 256)), dim3(256), 0, d->stream, d->reads, (u64)lo, (u64)hi, d->S, B.K[0], B.P[0]);
-    int cur = 0; int rc = partition_by_window(d, B, true, false, (u32)n, 0, 1ull << 9, false, cnt, base, nullptr, &cur, err, true); if (rc) return rc;
-    PtBufs C; C.M[0] = C.M[1] = nullptr; C.K[0] = B.K[cur]; C.P[0] = B.P[cur]; C.K[1] = B.K[cur ^ 1]; C.P[1] = B.P[cur ^ 1];
-    int cur2 = 0; rc = partition_by_window(d, C, true, false, (u32)n, 32 - lg, 1ull << lg, false, cnt, base, nullptr, &cur2, err); if (rc) return rc;
-    *order_out = C.P[cur2];
+    // one element format for all four passes, written by the minimiser kernel itself (round 2 had a pack and a re-key kernel in between): pass 1 sorts by
+    // the meta (dword 2), passes 2-4 by the hash (dword 0)
+    if (d->S == 4) hipLaunchKernelGGL((k_minimizer_t<4>), dim3(grid_for(n, 256)), dim3(256), 0, d->stream, d->reads, (u64)lo, (u64)hi, B.E[0]);
+    else if (d->S == 8) hipLaunchKernelGGL((k_minimizer_t<8>), dim3(grid_for(n, 256)), dim3(256), 0, d->stream, d->reads, (u64)lo, (u64)hi, B.E[0]);
+    else hipLaunchKernelGGL(k_minimizer, dim3(grid_for(n, 256)), dim3(256), 0, d->stream, d->reads, (u64)lo, (u64)hi, d->S, B.E[0]);
+    int cur = 0; int rc = partition_by_window(d, B, 2, (u32)n, 0, 1ull << 9, false, cnt, base, nullptr, &cur, err); if (rc) return rc;
+    PtBufs C; C.W = 3; C.E[0] = B.E[cur]; C.E[1] = B.E[cur ^ 1];
+    int cur2 = 0; rc = partition_by_window(d, C, 0, (u32)n, 32 - lg, 1ull << lg, false, cnt, base, nullptr, &cur2, err); if (rc) return rc;
+    *order_out = C.E[cur2];
     return 0;
 }
 static ProbeArgs base_args(Device* d) {
@@ -547,6 +569,7 @@ int dev_probe(Device* d, uint64_t lo, uint64_t hi, std::string& err) {
     HIPCHK(hipSetDevice(d->ordinal));
     if (!d->slots) { err = "index not built"; return SAGE2OV_ERR_ARG; }
     const u64 N = d->N;
+    { int rc = ensure_results(d, err); if (rc) return rc; }
     HIPCHK(hipEventRecord(d->ev[0], d->stream));
     HIPCHK(hipMemsetAsync(d->right, 0, (N + 1) * sizeof(u64), d->stream)); HIPCHK(hipMemsetAsync(d->left, 0, (N + 1) * sizeof(u64), d->stream));
     HIPCHK(hipMemsetAsync(d->conn, 0, (N + 1) * sizeof(u32), d->stream)); HIPCHK(hipMemsetAsync(d->cflag, 0, (N + 1) * sizeof(u32), d->stream));
@@ -664,6 +687,7 @@ int dev_probe(Device* d, uint64_t lo, uint64_t hi, std::string& err) {
     HIPCHK(hipEventRecord(d->ev[1], d->stream));
     HIPCHK(hipStreamSynchronize(d->stream));
     float ms = 0; hipEventElapsedTime(&ms, d->ev[0], d->ev[1]); d->tm.probe_ms += ms;
+    mem_sample(d);
     return 0;
 }
 
@@ -752,6 +776,12 @@ int dev_reciprocal(Device* d, uint64_t emit_lo, uint64_t emit_hi, uint64_t* n_ov
     HIPCHK(hipMemsetAsync(d->status, 0, N + 1, d->stream));
     hipLaunchKernelGGL(k_recip_cond, dim3(grid_for(N, 256 * COND_PER_THREAD)), dim3(256), 0, d->stream, N, d->right, d->left, d->conn, d->cflag, d->status, d->d_counters);
     HIPCHK(hipEventRecord(d->ev[4], d->stream));
+    if (d->diet && emit_hi > emit_lo) {                                     // the list is sized by a counting pass (capacity 0: nothing is written, the cursor counts)
+        hipLaunchKernelGGL(k_recip_emit, dim3(grid_for(emit_hi - emit_lo, 256 * EMIT_PER_THREAD)), dim3(256), 0, d->stream, N, d->reads, d->S, d->uniL, d->right, d->left, d->status, (EdgeCand*)nullptr, (u64)0, d->d_counters, (u64)emit_lo, (u64)emit_hi);
+        u64 want = 0; HIPCHK(hipMemcpyAsync(&want, d->d_counters, sizeof want, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
+        if (want + 1024 > d->cand_cap || !d->cand) { hipFree(d->cand); d->cand = nullptr; d->cand_cap = want + 1024; HIPCHK(hipMalloc(&d->cand, d->cand_cap * sizeof(EdgeCand))); }
+        HIPCHK(hipMemsetAsync(d->d_counters, 0, sizeof(u64), d->stream));
+    }
     if (emit_hi > emit_lo)
         hipLaunchKernelGGL(k_recip_emit, dim3(grid_for(emit_hi - emit_lo, 256 * EMIT_PER_THREAD)), dim3(256), 0, d->stream, N, d->reads, d->S, d->uniL, d->right, d->left, d->status, d->cand, d->cand_cap, d->d_counters, (u64)emit_lo, (u64)emit_hi);
     u64 c[8];
@@ -1254,6 +1284,7 @@ int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved
     HIPCHK(hipEventRecord(d->ev[1], d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
     float ms = 0; hipEventElapsedTime(&ms, d->ev[0], d->ev[1]); d->tm.hits_ms += ms;
     hipEventElapsedTime(&ms, d->ev[5], d->ev[1]); d->tm.marks_ms += ms;
+    mem_sample(d);
     return 0;
 }
 
@@ -1294,6 +1325,17 @@ int dev_unresolved_ids(Device* d, std::vector<uint32_t>& ids, std::string& err) 
     err = "unresolved id collection failed"; return SAGE2OV_ERR_INTERNAL;
 }
 
+int dev_meminfo(Device* d, uint64_t* out4, std::string& err) {
+    HIPCHK(hipSetDevice(d->ordinal));
+    size_t fr = 0, to = 0; HIPCHK(hipMemGetInfo(&fr, &to)); mem_sample(d);
+    u64 arena = 0; for (auto& b : d->ws) arena += b.cap;
+    if (getenv("SAGE2OV_MEMINFO")) {                                         // diagnostic: the big buffers of the arena, by workspace id (enum order)
+        fprintf(stderr, "[meminfo] free %.2f GB of %.2f, lowest %.2f, arena %.2f GB, N %llu, diet %d:", fr / 1e9, to / 1e9, d->memLow / 1e9, arena / 1e9, (unsigned long long)d->N, (int)d->diet);
+        for (int x = 0; x < WS_COUNT; x++) if (d->ws[x].cap >= (64u << 20)) fprintf(stderr, " ws%d=%.2f", x, d->ws[x].cap / 1e9);
+        fprintf(stderr, "\n");
+    }
+    out4[0] = fr; out4[1] = to; out4[2] = d->memLow; out4[3] = arena; return 0;
+}
 int dev_debug_table(Device* d, uint64_t* out5, std::string& err) {
     HIPCHK(hipSetDevice(d->ordinal));
     u64* dk = nullptr; HIPCHK(hipMalloc(&dk, 8 * sizeof(u64))); HIPCHK(hipMemsetAsync(dk, 0, 8 * sizeof(u64), d->stream));
@@ -1303,6 +1345,7 @@ int dev_debug_table(Device* d, uint64_t* out5, std::string& err) {
 }
 int dev_debug_keys(Device* d, uint64_t* out, std::string& err) {
     HIPCHK(hipSetDevice(d->ordinal));
+    if (!d->reads) { err = "the id-ordered read store has been released (memory-diet mode)"; return SAGE2OV_ERR_ARG; }
     u64* dk = nullptr; HIPCHK(hipMalloc(&dk, 8 * d->N * sizeof(u64)));
     hipLaunchKernelGGL(k_debug_keys, dim3(grid_for(4 * d->N, 256)), dim3(256), 0, d->stream, d->reads, (u64)d->N, d->S, d->h, dk);
     HIPCHK(hipStreamSynchronize(d->stream));
@@ -1406,6 +1449,8 @@ int dev_convert(Device* d, uint64_t* n_final, std::string& err) {
     HIPCHK(hipEventRecord(d->ev[1], d->stream));
     HIPCHK(hipStreamSynchronize(d->stream));
     float ms = 0; hipEventElapsedTime(&ms, d->ev[0], d->ev[1]); d->tm.convert_ms += ms;
+    mem_sample(d);
+    if (d->diet) for (int id : {WS_DEG, WS_OFFS, WS_CURSOR, WS_KEYS, WS_KEEP, WS_POS, WS_OWNER, WS_PARTIAL}) ws_free(d, id);
     *n_final = d->n_final;
     return 0;
 }

@@ -971,6 +971,7 @@ int sage2ov_overlap_reduce(sage2ov_ctx* c) {
 }
 
 int sage2ov_debug_table(sage2ov_ctx* c, uint64_t* out5) { if (!c || !out5 || !c->dev || !c->indexBuilt) return SAGE2OV_ERR_ARG; return dev_debug_table(c->dev, out5, c->err); }
+int sage2ov_debug_meminfo(sage2ov_ctx* c, uint64_t* out4) { if (!c || !out4 || !c->dev) return SAGE2OV_ERR_ARG; return dev_meminfo(c->dev, out4, c->err); }
 int sage2ov_debug_keys(sage2ov_ctx* c, uint64_t* out) { if (!c || !out || !c->dev || !c->organized) return SAGE2OV_ERR_ARG; return dev_debug_keys(c->dev, out, c->err); }
 // diagnostic (tests/tools): every read's verified hits as 5 x u32 rows {from, to, type, len, seq}, sorted by (from, seq)
 int sage2ov_debug_all_hits(sage2ov_ctx* c, uint32_t* out, uint64_t cap_rows, uint64_t* n_rows) {

@@ -73,6 +73,7 @@ int dev_export_cand_range(Device* d, void* dev_dst, uint64_t first, uint64_t n, 
 int dev_replace_cand_tail(Device* d, uint64_t keep, const void* dev_src, uint64_t n, std::string& err);
 // append host-computed edge candidates (from the reduce replay) to the device candidate list
 int dev_debug_table(Device* d, uint64_t* out5, std::string& err);
+int dev_meminfo(Device* d, uint64_t* out4, std::string& err);
 int dev_debug_keys(Device* d, uint64_t* out, std::string& err);
 int dev_debug_all_hits(Device* d, std::vector<Hit>& hits, std::string& err);
 int dev_append_edges(Device* d, const EdgeCand* e, uint64_t n, std::string& err);

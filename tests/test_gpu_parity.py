@@ -897,3 +897,25 @@ def test_mid_length_reads_in_repeats_match_oracle(pd, k, monkeypatch):
     g, o = run_gpu(m, bases, off), run_oracle(m, bases, off)
     assert_equals_oracle(g, o)
     g.close(); o.close()
+
+
+@pytest.mark.parametrize("name", ["g2_clean150_k40", "g3_noisy_rep_k21", "g4_highcopy_k21", "g5_mixedlen_k21"])
+def test_memory_diet_mode_matches_reference(name, tmp_path, monkeypatch):
+    """The mode a billion-read context runs in (BASELINE configs[4]): transient buffers released at the end of their phase, the id-ordered
+    read store released once the locality-ordered one exists (uniform lengths only: g5 keeps it), no minimiser groups, per-read results and the candidate
+    list allocated when first needed and sized by a counting pass.  Same files as the reference's, twice in a row (the second index build starts without
+    the id-ordered store), and the arena is smaller than the default mode's."""
+    m = fx.golden(name)
+    bases, off = fx.make_reads(m["synth"])
+    def run(diet):
+        monkeypatch.setenv("SAGE2OV_MEMORY_DIET", "1" if diet else "0")
+        c = s2.Context(m["k"], device=0)
+        c.reads_add_ascii(bases, off); c.reads_organize()
+        for rep in range(2):
+            c.run_steps23()
+            gp = str(tmp_path / f"d{int(diet)}{rep}.graph3"); c.graph_save(gp)
+            assert fx.graph3_matches(gp, name), f"diet={diet} pass {rep}"
+        rp = str(tmp_path / f"d{int(diet)}.reads"); c.reads_save(rp); assert fx.md5_file(rp) == m["reads_md5"]
+        arena = c.debug_meminfo()["arena"]; c.close()
+        return arena
+    assert run(True) < run(False)
