@@ -1,4 +1,5 @@
-"""The full-size digests (tests/golden/*_digest.json, written by oracle/make_digests.py from the pinned restatement).
+"""The full-size digests (tests/golden/*_digest.json, written by oracle/make_digests.py from the pinned restatement; BASELINE configs[1] and configs[2]
+additionally pinned on the reference binary's own run by oracle/pin_reference.py: reference_binary{graph3_md5, reads_md5, counters, seconds}).
 CPU: the committed small digests are reproduced by the oracle here (so digest code and oracle cannot drift apart unnoticed).
 GPU (-m gpu): the HIP path, through the C ABI, must reproduce every committed digest -- including BASELINE configs[1] (10 M reads),
 its noisy variant and configs[2] (50 M reads, the north-star target) -- counters, per-read records, edge list and P.graph3."""
@@ -59,6 +60,20 @@ def test_gpu_reproduces_full_size_digest(name, tmp_path):
     got["keys"] = want["keys"]
     bad = dg.compare(got, want)
     assert bad == [], f"{name}: " + "; ".join(bad)
+    if name in ("c1", "c2_1m", "c2", "c3"):
+        # these digests are pinned on the REFERENCE BINARY itself (oracle/make_digests.py for the small ones, oracle/pin_reference.py for BASELINE
+        # configs[1] and configs[2]: `SAGE2 -M 3` on the same reads, 46 minutes for the 50 M-read set): the device path's P.graph3 is the file the
+        # reference wrote, and so is its P.reads
+        assert want.get("reference_binary_graph3_identical") is True
+        rb = want.get("reference_binary")
+        if rb:
+            assert (got["graph3_md5"], got["graph3_bytes"]) == (rb["graph3_md5"], rb["graph3_bytes"])
+            rp = str(tmp_path / "t.reads"); ctx.reads_save(rp)
+            assert os.path.getsize(rp) == rb["reads_bytes"] and fx.md5_file(rp) == rb["reads_md5"], "P.reads differs from the reference binary's"
+            os.remove(rp)
+            st_, ost_ = ctx.reads_stats(), ctx.overlap_stats(); rc = rb["counters"]
+            assert (st_.unique_reads, st_.good_reads, ost_.contained_extension, ost_.contained_size, ost_.left_to_explore, ost_.edges_inserted, ost_.transitive_removed) == \
+                   (rc["unique_reads"], rc["good_reads"], rc["contained_extension"], rc["contained_size"], rc["left_to_explore"], rc["edges_inserted"], rc["transitive_removed"])
     # a second pass over the resident reads (atomics-ordered build) gives the same result
     ctx.run_steps23()
     got2 = dg.gpu_digest(ctx, cfg["synth"]["read_len"], with_reads=False); got2["keys"] = want["keys"]
