@@ -82,7 +82,7 @@ static void* ws_get(Device* d, int id, size_t bytes) {
     if (b.cap < bytes || !b.p) {
         if (b.p) hipFree(b.p);
         b.p = nullptr; b.cap = 0;
-        size_t want = bytes + bytes / 16 + 256;
+        size_t want = d->diet ? bytes + 256 : bytes + bytes / 16 + 256;        // (grow-only arena: 6 % of slack saves re-allocations; none when memory is what is short)
         if (hipMalloc(&b.p, want) != hipSuccess) { b.p = nullptr; return nullptr; }
         b.cap = want;
     }
@@ -321,6 +321,7 @@ static int build_locality_store(Device* d, std::string& err) {
     const u32* order = nullptr;
     if (N && !getenv("SAGE2OV_NO_LOCALITY")) { int rc = build_locality_order(d, 1, N + 1, &order, err); if (rc) return rc; }
     hipLaunchKernelGGL(k_loc_index, dim3(grid_for(std::max<u64>(N, 1), 256)), dim3(256), 0, d->stream, order, (u64)N, io, po, me);
+    if (d->diet) { HIPCHK(hipStreamSynchronize(d->stream)); ws_free(d, WS_MINH); ws_free(d, WS_OCUR); }       // the order's sort buffers (24 bytes per read) go before the tuples come
     hipLaunchKernelGGL(k_loc_scatter, dim3(grid_for((N + 1) * (d->S / 2), 256)), dim3(256), 0, d->stream, d->reads, po, (u64)N, d->S, rl);
     HIPCHK(hipGetLastError());
     return 0;
@@ -377,6 +378,12 @@ int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t
     //  this build would produce again -- the order is a function of the reads -- so they are kept)
     if (d->diet && d->reads && d->uniL) { HIPCHK(hipStreamSynchronize(d->stream)); hipFree(d->reads); d->reads = nullptr; }      // every later reader takes lengths from uniL
     const bool byPos = d->reads == nullptr;
+    if (d->diet) {                                                            // the previous step's results (per-read records, candidates, final edges: ~60 bytes per read) go before the sort's buffers come
+        HIPCHK(hipStreamSynchronize(d->stream));
+        hipFree(d->right); hipFree(d->left); hipFree(d->conn); hipFree(d->cflag); hipFree(d->status); hipFree(d->cand);
+        d->right = d->left = nullptr; d->conn = d->cflag = nullptr; d->status = nullptr; d->cand = nullptr; d->cand_cap = 0; d->n_cand = 0;
+        ws_free(d, WS_FINAL); d->final_edges = nullptr; d->n_final = 0; ws_free(d, WS_SLOW); ws_free(d, WS_SLOW2);
+    }
     d->T = std::max<u64>(IX_W, (8 * N + IX_W - 1) / IX_W * IX_W);            // load <= 0.5, as hashTable.cpp:83 sizes it; whole windows
     // (tests: SAGE2OV_TEST_TABLE_SLOTS forces a larger table, e.g. beyond 2^32 slots -- slot indices are 64-bit, pair indices and window ids 32-bit)
     if (const char* ev = getenv("SAGE2OV_TEST_TABLE_SLOTS")) { const u64 want = strtoull(ev, nullptr, 10); if (want > d->T) d->T = (want + IX_W - 1) / IX_W * IX_W; }

@@ -28,12 +28,13 @@ for s_ in range(steps):
                              overlaps=o.verified_overlaps, edges=o.edges, overlaps_per_s=o.verified_overlaps / dt,
                              mem_high_water_GB=(mi["total"] - mi["lowest_free"]) / 1e9, mem_total_GB=mi["total"] / 1e9, arena_GB=mi["arena"] / 1e9))
     print("[big]", json.dumps(out["steps"][-1]), flush=True)
+print(f"[big] downloading {ctx.overlap_stats().edges} edges for the property checks ({time.time() - t0:.0f} s)", flush=True)
 n = st.unique_reads
 e = ctx.edges()
 f, t, ty = e["from"].astype(np.int64), e["to"].astype(np.int64), e["type"].astype(np.int64)
 ok = dict(edges_n_minus_1=bool(len(e) == n - 1), from_lt_to=bool(np.all(f < t) and np.all(f >= 1) and np.all(t <= n)))
-key = (f << 34) | (t << 2) | ty
-ok["strictly_sorted"] = bool(np.all(key[1:] > key[:-1]))
+key = (f.astype(np.uint64) << np.uint64(34)) | (t.astype(np.uint64) << np.uint64(2)) | ty.astype(np.uint64)      # (ids reach 2^30: unsigned)
+ok["strictly_sorted"] = bool(np.all(key[1:] > key[:-1])); del key
 ok["lengths_in_range"] = bool(np.all(e["length"] > 0) and np.all(e["length"] < L) and np.all(e["length_twin"] > 0) and np.all(e["length_twin"] < L))
 src_end = (ty >> 1) & 1; dst_end = 1 - (ty & 1)
 use = np.bincount(2 * f + src_end, minlength=2 * (n + 1)) + np.bincount(2 * t + dst_end, minlength=2 * (n + 1))
