@@ -115,7 +115,11 @@ static void mem_sample(Device* d) { size_t fr = 0, to = 0; if (hipMemGetInfo(&fr
 // =============================================================================================
 // host-side launchers
 // =============================================================================================
+// one thread per item.  A launch of 2^32 threads or more does NOT fail on this runtime: its size is taken modulo 2^32 and the tail of the work silently
+// never runs (round 3, 1.02 G reads).  grid_for is therefore only for item counts that the documented limits keep below 2^32 (asserted in debug
+// builds by the limit checks of the callers: reads < 2^30, tuples < 2^32); kernels whose item count can pass it are grid-stride and use grid_for_capped.
 static inline unsigned grid_for(u64 n, unsigned block) { return (unsigned)std::max<u64>(1, (n + block - 1) / block); }
+static inline unsigned grid_for_capped(u64 n, unsigned block) { return (unsigned)std::max<u64>(1, std::min<u64>((n + block - 1) / block, ((1ull << 32) / block) - 1)); }
 
 Device* dev_create(int ordinal, std::string& err) {
     int count = 0;
@@ -264,7 +268,7 @@ int dev_organize_reads(Device* d, const uint64_t* pool, uint64_t pool_words, con
         hipLaunchKernelGGL(k_org_headpos, dim3(grid_for(n, 256)), dim3(256), 0, d->stream, flag, uid, (u64)n, headPos, (u64)N);
         HIPCHK(hipMalloc(&reads, (N + 1) * S * sizeof(u64))); HIPCHK(hipMalloc(&dfreq, (N + 1) * sizeof(unsigned short)));
         HIPCHK(hipMemsetAsync(reads, 0, S * sizeof(u64), d->stream)); HIPCHK(hipMemsetAsync(dfreq, 0, sizeof(unsigned short), d->stream));
-        hipLaunchKernelGGL(k_org_gather, dim3(grid_for(N * S, 256)), dim3(256), 0, d->stream, va, headPos, (u64)N, img, S, reads, dfreq);
+        hipLaunchKernelGGL(k_org_gather, dim3(grid_for_capped(N * S, 256)), dim3(256), 0, d->stream, va, headPos, (u64)N, img, S, reads, dfreq);
     } else {
         HIPCHK(hipMalloc(&reads, S * sizeof(u64))); HIPCHK(hipMalloc(&dfreq, sizeof(unsigned short)));
         HIPCHK(hipMemsetAsync(reads, 0, S * sizeof(u64), d->stream)); HIPCHK(hipMemsetAsync(dfreq, 0, sizeof(unsigned short), d->stream));
@@ -428,6 +432,13 @@ int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t
         int cur = 0;
         { int rc = partition_by_window(d, B, 0, n, IX_WPLOG, nW, doHist != 0, cnt, base, winOff, &cur, err); if (rc) return rc; }
         lap("partition by table window");
+        if (getenv("SAGE2OV_VERIFY_PARTITION") && n) {
+            u64* vo = nullptr; HIPCHK(hipMalloc(&vo, 3 * sizeof(u64))); HIPCHK(hipMemsetAsync(vo, 0, 3 * sizeof(u64), d->stream));
+            hipLaunchKernelGGL(k_pt_verify, dim3(grid_for(n, 256)), dim3(256), 0, d->stream, B.E[cur], n, IX_WPLOG, (u32)B.W, winOff, (u32)nW, vo);
+            u64 hv[3]; HIPCHK(hipMemcpyAsync(hv, vo, sizeof hv, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream)); hipFree(vo);
+            fprintf(stderr, "[verify-partition] %llu tuples, %llu windows: %llu order violations, largest window %llu tuples, %llu negative windows\n", (unsigned long long)n, (unsigned long long)nW,
+                    (unsigned long long)hv[0], (unsigned long long)hv[1], (unsigned long long)hv[2]);
+        }
         // ---- the windows of the uniform table, built in LDS; group tuples into the free buffer set
         IxWinArgs A; A.T = B.E[cur]; A.W = B.W; A.winOff = winOff; A.nW = (u32)nW; A.slots = d->slots; A.csr = d->csr;
         A.counters = d->d_counters + 8; A.big = big; A.big_cap = big_cap; A.idOf = d->idOf; A.G = wantMI ? B.E[cur ^ 1] : nullptr; A.wh = nullptr;     // (group tuples, 12 bytes each, into the free 16-byte buffer)
@@ -438,9 +449,12 @@ int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t
         hipLaunchKernelGGL(k_ix_window, dim3((unsigned)std::min<u64>(nW, 256ull * 6)), dim3(256), 0, d->stream, A);      // persistent: two rounds of 3 workgroups per CU, each with ONE pair of statistics atomics
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(c, d->d_counters + 8, sizeof c, hipMemcpyDeviceToHost, d->stream));
+        u64 c9 = 0; HIPCHK(hipMemcpyAsync(&c9, d->d_counters + 8 + 9, sizeof c9, hipMemcpyDeviceToHost, d->stream));
         HIPCHK(hipStreamSynchronize(d->stream));
         lap("table windows"); mem_sample(d);
-        if (c[8]) { err = "index build: a key occurs in more than 1 M reads, a table window overflowed, or the heavy windows' scratch ran out"; return SAGE2OV_ERR_LIMIT; }
+        if (c[8]) { char b_[256]; snprintf(b_, sizeof b_, "index build: %llu table windows overflowed, %llu keys occur in more than 1 M reads, %llu heavy windows found no scratch (cursor %llu of %llu)",
+                             (unsigned long long)(c[8] & 0xFFFFF), (unsigned long long)((c[8] >> 20) & 0xFFFFF), (unsigned long long)(c[8] >> 40), (unsigned long long)c9, (unsigned long long)A.wh_cap);
+                    err = b_; return SAGE2OV_ERR_LIMIT; }
         if (c[2] > big_cap) { err = "too many long buckets"; return SAGE2OV_ERR_LIMIT; }
         if (c[2]) {
             hipLaunchKernelGGL(k_index_purity, dim3(grid_for(c[2] * 64, 256)), dim3(256), 0, d->stream, d->readsLoc, d->S, d->h, big, c[2], d->csr, d->d_counters + 8);
@@ -554,7 +568,7 @@ static ProbeArgs base_args(Device* d) {
 
 template <int S, int NW, int WPL, int WPB, int HITS, int TAIL>
 static void launch_fast(Device* d, ProbeArgs& A, unsigned blocks) { hipLaunchKernelGGL((k_probe_fast<S, NW, WPL, WPB, HITS, TAIL>), dim3(blocks), dim3(64 * WPB), 0, d->stream, A); }
-// picks the instantiation for the resident reads; false: the 16-word layout has no fast kernel
+// picks the instantiation for the resident reads; false: the 32-word layout (505 .. 1018 bases) has no fast kernel
 template <int HITS, int TAIL>
 static bool launch_fast_any(Device* d, ProbeArgs& A, unsigned blocks) {
     constexpr int FW = SAGE2OV_FAST_WPB;      // waves per block: a whole CU's worth works on one locality chunk
@@ -565,6 +579,10 @@ static bool launch_fast_any(Device* d, ProbeArgs& A, unsigned blocks) {
     // (the 16-dword layout's state-machine rows take 12 KB of LDS per wave: four waves per block keep three blocks on a CU)
     else if (d->S == 8 && nwinMax <= 128) launch_fast<8, 16, 2, ((HITS || !TAIL) ? FW : 4), HITS, TAIL>(d, A, blocks);
     else if (d->S == 8) launch_fast<8, 16, 4, ((HITS || !TAIL) ? FW : 4), HITS, TAIL>(d, A, blocks);
+    // 16-word layout (252 .. 504 bases, round 3): 20-dword compares and five windows per lane up to 320 bases / 320 windows (2 x 300 MiSeq reads), 32-dword
+    // compares and eight windows per lane beyond; blocks of four waves (the state machine's rows take 10 / 18 KB of LDS per wave)
+    else if (d->S == 16 && d->maxL <= 320 && nwinMax <= 320) launch_fast<16, 20, 5, 4, HITS, TAIL>(d, A, blocks);
+    else if (d->S == 16 && nwinMax <= 512) launch_fast<16, 32, 8, 4, HITS, TAIL>(d, A, blocks);
     else return false;
     return true;
 }
@@ -654,7 +672,7 @@ int dev_probe(Device* d, uint64_t lo, uint64_t hi, std::string& err) {
             int rc = timed([&] { launched = tailKernel == 2 ? launch_fast_any<0, 2>(d, Aw, nb) : (tailKernel == 1 ? launch_fast_any<0, 1>(d, Aw, nb) : launch_fast_any<0, 0>(d, Aw, nb)); }); if (rc) return rc;
             if (armed && launched) { int rca = close_prehits(); if (rca) return rca; }
         }
-        if (!launched) {                                                       // 16-word layout: sequential kernel only (for now)
+        if (!launched) {                                                       // 32-word layout: sequential kernel only
             HIPCHK(hipEventRecord(d->ev[2], d->stream));
             int rc = launch_probe<0>(d, A, err); if (rc) return rc;
             HIPCHK(hipEventRecord(d->ev[3], d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
@@ -1346,7 +1364,7 @@ int dev_meminfo(Device* d, uint64_t* out4, std::string& err) {
 int dev_debug_table(Device* d, uint64_t* out5, std::string& err) {
     HIPCHK(hipSetDevice(d->ordinal));
     u64* dk = nullptr; HIPCHK(hipMalloc(&dk, 8 * sizeof(u64))); HIPCHK(hipMemsetAsync(dk, 0, 8 * sizeof(u64), d->stream));
-    hipLaunchKernelGGL(k_debug_table, dim3(grid_for(d->T, 256)), dim3(256), 0, d->stream, d->slots, (u64)d->T, dk);
+    hipLaunchKernelGGL(k_debug_table, dim3(grid_for_capped(d->T, 256)), dim3(256), 0, d->stream, d->slots, (u64)d->T, dk);
     HIPCHK(hipStreamSynchronize(d->stream));
     HIPCHK(hipMemcpy(out5, dk, 5 * sizeof(u64), hipMemcpyDeviceToHost)); hipFree(dk); return 0;
 }

@@ -322,7 +322,11 @@ def test_hashtable_file_from_a_device_organised_context(name, tmp_path):
     (dict(seed=32, genome_len=30000, n_reads=9000, read_len=200, read_len_min=120, err_ppm=500), 31),   # mixed lengths in the long layout
     (dict(seed=33, genome_len=24000, n_reads=8000, read_len=150, err_ppm=0), 21),          # 130 windows: 3 windows per lane, 10-dword compare
     (dict(seed=36, genome_len=24000, n_reads=8000, read_len=150, err_ppm=2000), 22),       # the same with read errors: in-kernel state machine with 3 windows per lane
-    (dict(seed=34, genome_len=40000, n_reads=6000, read_len=300, err_ppm=300), 55),        # 16-word slots: sequential kernel only
+    (dict(seed=34, genome_len=40000, n_reads=6000, read_len=300, err_ppm=300), 55),        # 16-word slots (252 .. 504 bases): fast kernel with 20-dword compares, five windows per lane (round 3)
+    (dict(seed=37, genome_len=60000, n_reads=9000, read_len=300, err_ppm=0), 40),          # 2 x 300 reads, error-free: the consistent path of that instantiation, 261 windows
+    (dict(seed=38, genome_len=50000, n_reads=6000, read_len=320, read_len_min=255, err_ppm=1500, n_repeat_families=2, repeat_copies=6, repeat_len=600), 31),   # its state machine, mixed lengths across the 8-/16-word boundary
+    (dict(seed=39, genome_len=60000, n_reads=5000, read_len=504, read_len_min=330, err_ppm=800), 64),     # 32-dword compares, eight windows per lane, the longest read of the layout
+    (dict(seed=40, genome_len=50000, n_reads=4000, read_len=450, err_ppm=0), 21),          # 430 windows
     (dict(seed=35, genome_len=12000, n_reads=9000, read_len=60, err_ppm=0), 15),           # short reads, h < 16 (minimiser width = h)
 ])
 def test_other_kernel_instantiations_match_oracle(pd, k):
