@@ -9,7 +9,10 @@
 #include <fstream>
 #include <iostream>
 #include <string>
+#include <memory>
+#include <vector>
 #include "sage2ov.hpp"
+#include "sage2ov_multi.h"
 
 using namespace std;
 using namespace sage2ov;
@@ -22,20 +25,25 @@ static void printListOfArgs() {
     cout << "\t-f|--fileInput <string>\tinterleaved FASTA/FASTQ(.gz)\n\t-l|--listInput <string>\tlist file (f1=/f2=/f=)\n"
             "\t-k|--minOverlap <int>\tminimum overlap (required)\n\t-o|--outputDir <string>\n\t-p|--prefix <string>\t[untitled]\n"
             "\t-i|--inputPrefix <string>\t[prefix]\n\t-m|--minStep <int>\t[1]\n\t-M|--maxStep <int>\t[3] (4 = simplified graph P.graph4; steps 5-7: run SAGE2 -m 5 on the files written here)\n"
-            "\t-s|--saveAll\n\t-d|--debug\n\t-g|--gpu <int>\tHIP device ordinal [0]\n\t-h|--help\n\n";
+            "\t-s|--saveAll\n\t-d|--debug\n\t-g|--gpu <int>\tHIP device ordinal [0]\n"
+            "\t-G|--gpus <int>\tsteps 2-3 on this many GPUs of the node (devices gpu .. gpu+G-1): reads and index replicated, probe pass\n"
+            "\t\t\trange-partitioned, records / flags / edge and survivor buckets exchanged with RCCL over xGMI [1]\n\t-h|--help\n\n";
 }
 static string trimBack(string s, const string& pat) { size_t e = s.find_last_not_of(pat); return e == string::npos ? "" : s.substr(0, e + 1); }
 static double now() { return chrono::duration<double>(chrono::steady_clock::now().time_since_epoch()).count(); }
 
 int main(int argc, char* argv[]) {
-    int minStep = 1, maxStep = 3, gpu = 0; unsigned minOverlap = 0; bool saveAll = false, debugging = false, fFlag = false, lFlag = false;
+    int minStep = 1, maxStep = 3, gpu = 0, gpus = 1; bool shareGpu = false, forceMulti = false; unsigned minOverlap = 0; bool saveAll = false, debugging = false, fFlag = false, lFlag = false;
     string fileInput, listInput, outputDir, prefixName = "untitled", inputPrefix;
     static struct option opts[] = {{"help", no_argument, 0, 'h'}, {"fileInput", required_argument, 0, 'f'}, {"minOverlap", required_argument, 0, 'k'},
         {"listInput", required_argument, 0, 'l'}, {"outputDir", required_argument, 0, 'o'}, {"prefix", required_argument, 0, 'p'},
         {"inputPrefix", required_argument, 0, 'i'}, {"minStep", required_argument, 0, 'm'}, {"maxStep", required_argument, 0, 'M'},
-        {"saveAll", no_argument, 0, 's'}, {"debug", no_argument, 0, 'd'}, {"gpu", required_argument, 0, 'g'}, {0, 0, 0, 0}};
+        {"saveAll", no_argument, 0, 's'}, {"debug", no_argument, 0, 'd'}, {"gpu", required_argument, 0, 'g'}, {"gpus", required_argument, 0, 'G'},
+        {"share-gpu", no_argument, 0, 1001},      // rehearsal: all ranks on device `gpu`, exchanges by device copies instead of RCCL (a box with fewer GPUs than ranks)
+        {"force-multi", no_argument, 0, 1002},    // the multi-GPU code path (RCCL communicator, the four exchanges) even with one GPU
+        {0, 0, 0, 0}};
     int c, oi = 0;
-    while ((c = getopt_long(argc, argv, "hf:l:k:o:p:i:m:M:sdg:", opts, &oi)) != -1) {
+    while ((c = getopt_long(argc, argv, "hf:l:k:o:p:i:m:M:sdg:G:", opts, &oi)) != -1) {
         switch (c) {
             case 'h': cout << "\n"; printUsage(); printListOfArgs(); exit(0);
             case 'f': fileInput = optarg; fFlag = true; break;
@@ -49,6 +57,9 @@ int main(int argc, char* argv[]) {
             case 's': saveAll = true; break;
             case 'd': debugging = true; break;
             case 'g': gpu = atoi(optarg); break;
+            case 'G': gpus = atoi(optarg); if (gpus < 1) gpus = 1; break;
+            case 1001: shareGpu = true; break;
+            case 1002: forceMulti = true; break;
             case '?': cout << "\n"; exit(0);
             default: cout << "[ERROR] Wrong command line arguments!\n\n"; exit(0);
         }
@@ -72,7 +83,8 @@ int main(int argc, char* argv[]) {
               << "***********************************************************************************************************\n\n";
     const int lastStep = maxStep > 4 ? 4 : maxStep;
     try {
-        Context ctx((uint16_t)minOverlap, lastStep == 1 ? SAGE2OV_DEVICE_NONE : gpu);
+        const bool multi = (gpus > 1 || forceMulti) && lastStep >= 3 && minStep <= 3;
+        Context ctx((uint16_t)minOverlap, lastStep == 1 ? SAGE2OV_DEVICE_NONE : gpu, 0, 0, multi ? (unsigned)gpus : 1u);
         ReadLoader loaderObj(ctx);
         double t0 = now();
         if (minStep <= 1) {                                                                  // main.cpp:37-61
@@ -99,6 +111,35 @@ int main(int argc, char* argv[]) {
             OverlapGraph graphObj(&loaderObj);
             graphObj.loadOverlapGraphFromFile(outputDir + inputPrefix + ".graph3");
             step4(graphObj);
+        } else if (multi) {
+            // steps 2-3 on `gpus` GPUs (sage2ov_multi.cpp): rank 0 = this context; the others import the organised read store
+            t0 = now();
+            vector<unique_ptr<Context>> others; vector<sage2ov_ctx*> all{ctx.get()}; vector<int> devs{gpu};
+            {
+                auto s = loaderObj.stats();
+                vector<uint64_t> words((s.unique_reads + 1) * (uint64_t)s.words_per_read); vector<uint16_t> freq(s.unique_reads + 1);
+                ctx.check(sage2ov_reads_export_words(ctx.get(), words.data(), words.size(), freq.data()));
+                for (int r = 1; r < gpus; r++) {
+                    const int dev = shareGpu ? gpu : gpu + r;
+                    others.emplace_back(new Context((uint16_t)minOverlap, dev, 0, (unsigned)r, (unsigned)gpus));
+                    others.back()->check(sage2ov_reads_import_words(others.back()->get(), words.data(), s.unique_reads, s.words_per_read, s.max_read_length, freq.data(), s.good_reads, s.total_bp));
+                    all.push_back(others.back()->get()); devs.push_back(dev);
+                }
+            }
+            string merr; int mrc = sage2ov_multi::run_steps23(all, devs, shareGpu, merr);
+            if (mrc) throw Error(mrc, merr);
+            sage2ov_index_stats is{}; ctx.check(sage2ov_index_stats_get(ctx.get(), &is)); sage2ov_overlap_stats os{}; ctx.check(sage2ov_overlap_stats_get(ctx.get(), &os));
+            logStream << "STEPS 2-3 on " << gpus << (shareGpu ? " ranks sharing GPU " : " GPUs starting at ") << gpu << (shareGpu ? " (rehearsal transport)" : " (RCCL)") << "\n\t         Hash string length: " << is.hash_string_length
+                      << "\n\t            Hash table size: " << is.slots << "\n\t Number of hash elements over threshold: " << is.long_buckets
+                      << "\n     Total contained by extension: " << os.contained_extension << "\n          Total contained by size: " << os.contained_size
+                      << "\n            Total left to explore: " << os.left_to_explore << "\n              Verified overlaps: " << os.verified_overlaps
+                      << "\n     Total edges inserted: " << os.edges_inserted << "\n  Transitive edge removed: " << os.transitive_removed << "\n     Edges in the graph: " << os.edges
+                      << "\n\tSteps 2-3 in " << now() - t0 << " sec.\n";
+            OverlapGraph graphObj(&loaderObj);
+            if (minStep == 1 && !saveAll) { double tw = now(); loaderObj.saveReadsInFile(outputDir + prefixName + ".reads"); logStream << "\t" << prefixName << ".reads written in " << now() - tw << " sec.\n"; }
+            if (saveAll) { HashTable hashObj(&loaderObj); hashObj.saveHashTableInFile(outputDir + prefixName + ".hashTable"); }
+            if (lastStep == 3 || saveAll) { double tw = now(); graphObj.saveOverlapGraphInFile(outputDir + prefixName + ".graph3"); logStream << "\t" << prefixName << ".graph3 written in " << now() - tw << " sec.\n"; }
+            if (lastStep >= 4) step4(graphObj);
         } else if (lastStep >= 2) {
             HashTable hashObj(&loaderObj);
             t0 = now(); hashObj.hashPrefixesAndSuffix();                                      // main.cpp:76-77 (always rebuilt: P.hashTable is not read)

@@ -1,9 +1,9 @@
-"""diagnostic: step time per read for several read lengths, clean and with 0.1 % errors (the 16-dword layouts have no in-kernel tail)"""
+"""diagnostic: step time per read for several read lengths, clean and with 0.1 % errors.  usage: read_lengths.py [n_reads] [L ...]"""
 import os, sys, time
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 import fixtures as fx, sage2_amd as s2
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
-for L in (100, 150, 200, 250):
+for L in ([int(x) for x in sys.argv[2:]] or (100, 150, 200, 250, 300, 400, 500)):
     for err in (0, 1000):
         pd = dict(seed=5, genome_len=n * L // 50, n_reads=n, read_len=L, err_ppm=err)
         bases, off = fx.make_reads(pd)

@@ -63,3 +63,26 @@ def test_bench_starts_its_own_ranks_without_a_launcher():
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     a = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][-1])
     assert a["n_gpus"] == 2 and a["world_size"] == 2 and a["collectives"] == "gloo"
+
+
+@pytest.mark.parametrize("name,gpus,flags", [("g5_mixedlen_k21", 2, ["--share-gpu"]), ("g3_noisy_rep_k21", 3, ["--share-gpu"]), ("g4_highcopy_k21", 2, ["--share-gpu"]),
+                                             ("g2_clean150_k40", 1, ["--force-multi"]), ("g3_noisy_rep_k21", 1, ["--force-multi"])])
+def test_cli_multi_gpu_mode_writes_reference_files(name, gpus, flags, tmp_path):
+    """`sage2ov --gpus G`: the C++ host driver of the multi-GPU path (sage2_amd/csrc/sage2ov_multi.cpp: one thread and one context per rank, the four
+    exchanges).  With --share-gpu all ranks run on the one GPU of the test box and exchange by device copies; with --force-multi one rank goes through
+    RCCL itself (ncclCommInitAll, ncclAllGather, ncclAllReduce).  P.reads and P.graph3 must be the reference's files either way."""
+    import fixtures as fx, sage2_amd as s2
+    m = fx.golden(name)
+    fa = str(tmp_path / "x.fa"); s2.synth_write_fasta(fx.synth_params(m["synth"]), fa)
+    out = str(tmp_path / "out")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([os.path.join(ROOT, "sage2_amd", "sage2ov"), "-f", fa, "-k", str(m["k"]), "-o", out, "-p", "t", "-M", "3", "-G", str(gpus)] + flags,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout.decode()[-2000:]
+    assert fx.md5_file(os.path.join(out, "t.reads")) == m["reads_md5"]
+    assert fx.graph3_matches(os.path.join(out, "t.graph3"), name)
+    log = open(os.path.join(out, "t.log")).read()
+    assert f"STEPS 2-3 on {gpus}" in log and ("(RCCL)" in log) == ("--force-multi" in flags)
+    for key, lab in (("contained_extension", "Total contained by extension"), ("transitive_removed", "Transitive edge removed")):
+        if key in m["counters"]:
+            assert f"{lab}: {m['counters'][key]}" in log
