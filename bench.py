@@ -221,6 +221,7 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--cpu-port", action="store_true", help="time the CPU restatement instead of oracle/_ref")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-scaling-model", action="store_true", help="skip the multi-GPU model and the extra build + probe pass without minimiser groups it measures (profiling runs)")
     ap.add_argument("--no-noisy-variant", action="store_true", help="skip the secondary line: the same workload with 0.1 %% substitution errors (SURVEY 8d)")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -375,6 +376,24 @@ def main():
                     traffic, traffic_src = te.get("bytes_per_launch"), te.get("source")
             except Exception:
                 traffic = None
+        # the bound the kernel is actually on: vector-instruction issue.  Wave-instructions per read come from a committed PMC pass of THIS kernel source
+        # (profiles/probe_insts.json, keyed by a hash of the kernel's source: stale -> null); peak = one VALU wave-instruction per SIMD every 2 cycles
+        # (MI355X_MICROARCH.md: SIMD-32, a wave64 instruction issues over 2 cycles) x 4 SIMDs x 256 CUs x 2.4 GHz
+        valu = None
+        ij = os.path.join(ROOT, "profiles", "probe_insts.json")
+        if os.path.exists(ij) and args.err_ppm == 0 and world == 1 and kern_ms > 0:
+            try:
+                import hashlib
+                ie = json.load(open(ij)).get(f"{args.reads}x{args.read_len}_k{args.k}_seed{args.seed}", {})
+                sha = hashlib.sha1(b"".join(open(os.path.join(ROOT, "sage2_amd", "csrc", nm), "rb").read() for nm in ("kernels_probe_fast.inc", "kernels_common.inc"))).hexdigest()
+                if ie.get("kernel_source_sha1") == sha:
+                    peak = 256 * 4 * 2.4e9 / 2.0
+                    achieved = ie["valu_per_read"] * st.unique_reads / (kern_ms * 1e-3)
+                    valu = {"wave_insts_per_read": ie["valu_per_read"], "scalar_insts_per_read": ie["salu_per_read"], "lds_insts_per_read": ie["lds_per_read"], "vmem_insts_per_read": ie["vmem_rd_per_read"],
+                            "issue_peak": peak, "achieved": achieved, "unit": "VALU wave-instructions/s", "frac": achieved / peak,
+                            "note": "peak counts every VALU instruction at 2 cycles; three-source, 64-bit and quarter-rate integer instructions cost more (DESIGN 5.2)", "source": ie.get("source")}
+            except Exception:
+                valu = None
         res = {
             "metric": "overlaps/sec + edge-set bit-identity vs OpenMP ref, 150 bp reads k=40",
             "value": value, "unit": "overlaps/s", "n_gpus": world, "world_size": (dist.get_world_size() if dist is not None else 1),
@@ -401,6 +420,7 @@ def main():
                          "limiter": "instruction issue (about 810 VALU + 480 scalar wave-instructions per read: the vector ALUs are 70 % busy at four waves per SIMD) and the one dependent table look-up per read that four waves cannot hide; memory-side traffic is below the algorithmic bytes since the locality-ordered store and window reuse (DESIGN.md 5.2)",
                          # a probe pass is up to three launches of the kernel: a sample of 1/128 of the range, the rest (the instantiation the sample picked), and the
                          # few reads the first two listed; kernel_ms and the bytes are those of the whole pass (sum over its launches)
+                         "valu": valu,
                          "kernel_ms": kern_ms, "kernel_launches_per_pass": pk_f / max(pk_n, 1), "algorithmic_bytes_per_launch": a_probe * share,
                          "whole_path_achieved": a_total / (elapsed / args.steps) / 1e9, "whole_path_frac": a_total / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
         }
@@ -410,7 +430,7 @@ def main():
             t4 = time.perf_counter(); c.graph_simplify(); w4 = time.perf_counter() - t4; s4 = c.simplify_stats()     # (the second call first frees the first one's result)
             return {"device_ms": s4.device_ms, "wall_ms_first_call": 1e3 * w41, "wall_ms": 1e3 * w4, "nodes_contracted": s4.nodes_contracted, "removed": s4.removed, "loop_iterations": s4.loop_iterations,
                     "edges_left": s4.edges, "reads_on_edges": s4.reads_on_edges}
-        if world == 1 and not sharded:
+        if world == 1 and not sharded and not args.no_scaling_model:
             # what a rank of a multi-GPU run would do differently: no minimiser groups once it probes fewer than 24 M reads -- measured here (one untimed
             # build + probe pass with the groups switched off), then the model
             alt = None

@@ -58,4 +58,19 @@ if pk:
                     "read_requests_128B": r128, "kernel": k, "source": f"profiles/{tag}_pmc_summary.txt",
                     "note": "per probe pass (sum over the pass's launches of the kernel); reads = TCC_EA0_RDREQ_128B x 128 B (all read requests are 128-byte lines; FETCH_SIZE tallies them at 64 B, cf. MI355X_MICROARCH.md HBM section)"}
         json.dump(cur, open(tj, "w"), indent=1)
+# instruction counts of the probe pass per read (SQ_INSTS_* are wave-instructions): what bench.py's roofline.valu is computed from
+if pk and any(c == "SQ_INSTS_VALU" for (_, c) in acc):
+    import hashlib, re
+    def per_read(c):
+        passes = max(cnt.get(("s2::k_ix_window", c), 0), 1)
+        return sum(acc.get((kk, c), 0) for kk in pk) / passes / N
+    m = re.match(r"(\d+) x (\d+) bp .*?k=(\d+).*?seed (\d+)", bench["config"]["workload"])
+    key = f"{m.group(1)}x{m.group(2)}_k{m.group(3)}_seed{m.group(4)}"
+    ij = os.path.join(prof, "probe_insts.json")
+    cur = json.load(open(ij)) if os.path.exists(ij) else {}
+    src_sha = hashlib.sha1(b"".join(open(os.path.join(root, "sage2_amd", "csrc", n), "rb").read() for n in ("kernels_probe_fast.inc", "kernels_common.inc"))).hexdigest()
+    cur[key] = {"kernel_source_sha1": src_sha, "valu_per_read": per_read("SQ_INSTS_VALU"), "salu_per_read": per_read("SQ_INSTS_SALU"), "lds_per_read": per_read("SQ_INSTS_LDS"),
+                "vmem_rd_per_read": per_read("SQ_INSTS_VMEM_RD"), "wave_quad_cycles_per_read": per_read("SQ_WAVE_CYCLES"), "kernel": " + ".join(pk), "source": f"profiles/{tag}_pmc_summary.txt",
+                "note": "wave-instructions of the probe pass (all launches of k_probe_fast<..., HITS = 0, .>) per unique read, rocprofv3 --pmc SQ_INSTS_*"}
+    json.dump(cur, open(ij, "w"), indent=1)
 print("ok")

@@ -4,7 +4,7 @@
 set -e
 export TMPDIR=/tmp
 R=$PWD; O=$R/gpurun_out/c2; mkdir -p $O
-ARGS="--reads 10000000 --no-cpu-baseline --no-noisy-variant --no-step4 --steps 5 --warmup 1"     # configs[1] (bench.py defaults to configs[2])
+ARGS="--reads 10000000 --no-cpu-baseline --no-noisy-variant --no-step4 --no-scaling-model --steps 5 --warmup 1"     # configs[1] (bench.py defaults to configs[2])
 cd $R
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o c2 -- python3 bench.py $ARGS > $O/bench_stats.log 2>&1
 echo stats done

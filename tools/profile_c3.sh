@@ -4,7 +4,7 @@
 set -e
 export TMPDIR=/tmp
 R=$PWD; O=$R/gpurun_out/c3; mkdir -p $O
-ARGS="--no-cpu-baseline --no-noisy-variant --no-c2 --no-step4 --steps 3 --warmup 1"     # bench.py defaults to configs[2] (50 M reads, seed 3)
+ARGS="--no-cpu-baseline --no-noisy-variant --no-c2 --no-step4 --no-scaling-model --steps 3 --warmup 1"     # bench.py defaults to configs[2] (50 M reads, seed 3)
 cd $R
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o c3 -- python3 bench.py $ARGS > $O/bench_stats.log 2>&1
 echo stats done
@@ -14,4 +14,6 @@ timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_b -o 
 echo pmc b done
 timeout -k 10 200 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum --output-format csv -d $O/pmc_c -o c3 -- python3 bench.py $ARGS > $O/bench_pmc_c.log 2>&1
 echo pmc c done
+timeout -k 10 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES --output-format csv -d $O/pmc_d -o c3 -- python3 bench.py $ARGS > $O/bench_pmc_d.log 2>&1
+echo pmc d done
 grep '^{' $O/bench_stats.log | cut -c1-300
