@@ -502,6 +502,15 @@ def main():
             res["cpu_baseline"] = cpu_baseline_subprocess(args)
             if res["cpu_baseline"]:
                 res["speedup_vs_cpu_baseline"] = value / res["cpu_baseline"]["value"]
+                rb = (want or {}).get("reference_binary")
+                if rb:
+                    # the reference binary on THIS input (not a sample): recorded when the digest was pinned (oracle/pin_reference.py, build container) -- the
+                    # "same input" CPU figure of SURVEY 8(d), from the reference's own log (1-s resolution); not measured on this host, not used for the speed-up
+                    fs = rb.get("function_seconds", {})
+                    t23 = sum(fs.get(kk, 0) for kk in ("hashPrefixesAndSuffix", "buildInitialOverlapGraph", "buildOverlapGraphEconomy", "sortEdgesEconomy", "convertGraph"))
+                    if t23:
+                        res["cpu_baseline"]["reference_on_this_input"] = {"value": ost.verified_overlaps / t23, "unit": "overlaps/s", "seconds_steps_2_3": t23, "function_seconds": fs,
+                                                                         "threads": rb.get("threads"), "peak_rss_gb": rb.get("peak_rss_gb"), "where": "recorded: build container, oracle/pin_reference.py (not this host)"}
         print(json.dumps(res), flush=True)
     if sharded:
         dist.barrier()
