@@ -190,7 +190,7 @@ int dev_upload_reads(Device* d, const uint64_t* words, uint64_t N, int S, int mi
 }
 
 static int scan_u32(Device* d, const u32* in, u64 n, u32* out, u64* total, std::string& err);
-struct PtBufs { u32* E[2]; int W; };      // two buffers of n tuples of W dwords each (kernels_partition.inc)
+struct PtBufs { u32* E[2]; int W; const u32* src0 = nullptr; };      // two buffers of n tuples of W dwords each (kernels_partition.inc); src0: the first pass reads the tuples there (left untouched) and writes E[0]
 static int partition_by_window(Device* d, PtBufs& B, int keyw, u32 n, int shiftW, u64 nWin, bool digit0Counted, u32* cnt, u32* base, u32* off, int* cur_out, std::string& err);
 // Step 1 on the device: see k_org_canon.  On return the read store is resident exactly as after dev_upload_reads, and the
 // host receives the image (for the .reads writer, lengths) and the frequencies.
@@ -349,16 +349,18 @@ static int partition_by_window(Device* d, PtBufs& B, int keyw, u32 n, int shiftW
     int cur = 0;
     if (n) {
         const int bper = nd ? (wb + nd - 1) / nd : 0;
+        const u32* in = B.src0 ? B.src0 : B.E[0];
+        if (B.src0 && nd == 0) { HIPCHK(hipMemcpyAsync(B.E[0], B.src0, (size_t)n * B.W * sizeof(u32), hipMemcpyDeviceToDevice, d->stream)); in = B.E[0]; }
         for (int j = 0; j < nd; j++) {
             const int shift = shiftW + j * bper; const int bj = std::min(bper, wb - j * bper); const u32 mask = (1u << bj) - 1u;
-            if (!(j == 0 && digit0Counted)) hipLaunchKernelGGL(k_pt_hist, dim3(ntiles), dim3(PT_THREADS), 0, d->stream, B.E[cur] + keyw, n, shift, mask, cnt, ntiles, (u32)B.W);
+            if (!(j == 0 && digit0Counted)) hipLaunchKernelGGL(k_pt_hist, dim3(ntiles), dim3(PT_THREADS), 0, d->stream, in + keyw, n, shift, mask, cnt, ntiles, (u32)B.W);
             int rc = scan_u32_async(d, cnt, (u64)(mask + 1) * ntiles, base, err); if (rc) return rc;
-            const int o = cur ^ 1;
-            if (B.W == 4 && keyw == 0) hipLaunchKernelGGL((k_pt_scatter<4, 0>), dim3(ntiles), dim3(PT_THREADS), 0, d->stream, B.E[cur], n, shift, mask, base, ntiles, B.E[o]);
-            else if (B.W == 3 && keyw == 0) hipLaunchKernelGGL((k_pt_scatter<3, 0>), dim3(ntiles), dim3(PT_THREADS), 0, d->stream, B.E[cur], n, shift, mask, base, ntiles, B.E[o]);
-            else if (B.W == 3 && keyw == 2) hipLaunchKernelGGL((k_pt_scatter<3, 2>), dim3(ntiles), dim3(PT_THREADS), 0, d->stream, B.E[cur], n, shift, mask, base, ntiles, B.E[o]);
+            const int o = (j == 0 && B.src0) ? 0 : (cur ^ 1);
+            if (B.W == 4 && keyw == 0) hipLaunchKernelGGL((k_pt_scatter<4, 0>), dim3(ntiles), dim3(PT_THREADS), 0, d->stream, in, n, shift, mask, base, ntiles, B.E[o]);
+            else if (B.W == 3 && keyw == 0) hipLaunchKernelGGL((k_pt_scatter<3, 0>), dim3(ntiles), dim3(PT_THREADS), 0, d->stream, in, n, shift, mask, base, ntiles, B.E[o]);
+            else if (B.W == 3 && keyw == 2) hipLaunchKernelGGL((k_pt_scatter<3, 2>), dim3(ntiles), dim3(PT_THREADS), 0, d->stream, in, n, shift, mask, base, ntiles, B.E[o]);
             else { err = "partition: unsupported tuple format"; return SAGE2OV_ERR_INTERNAL; }
-            cur = o;
+            cur = o; in = B.E[o];
         }
         if (off) hipLaunchKernelGGL(k_pt_bounds, dim3(grid_for(n, 256)), dim3(256), 0, d->stream, B.E[cur] + keyw, n, shiftW, (u32)nWin, off, (u32)B.W);
     } else if (off) HIPCHK(hipMemsetAsync(off, 0, (nWin + 1) * sizeof(u32), d->stream));
@@ -717,15 +719,16 @@ int dev_probe(Device* d, uint64_t lo, uint64_t hi, std::string& err) {
 }
 
 struct Record { u64 right, left; u32 conn, cflag; };
-// (a rank probes a range of POSITIONS of the locality order; the per-read arrays are indexed by id)
-__global__ void k_pack_records(u64 lo, u64 hi, const u32* __restrict__ idOf, const u64* right, const u64* left, const u32* conn, const u32* cflag, Record* out) {
+// (a rank probes a range of POSITIONS of the locality order; since round 3 the per-read arrays are indexed by position too and name neighbours by position --
+//  every rank computes the same order -- so a rank's records are a contiguous slice)
+__global__ void k_pack_records(u64 lo, u64 hi, const u64* right, const u64* left, const u32* conn, const u32* cflag, Record* out) {
     u64 p = lo + (u64)blockIdx.x * blockDim.x + threadIdx.x; if (p >= hi) return;
-    const u32 i = idOf[p]; Record r; r.right = right[i]; r.left = left[i]; r.conn = conn[i]; r.cflag = cflag[i]; out[p - lo] = r;
+    Record r; r.right = right[p]; r.left = left[p]; r.conn = conn[p]; r.cflag = cflag[p]; out[p - lo] = r;
 }
-__global__ void k_unpack_records(u64 first, u64 n, const u32* __restrict__ idOf, const Record* in, u64* right, u64* left, u32* conn, u32* cflag, bool own) {
+__global__ void k_unpack_records(u64 first, u64 n, const Record* in, u64* right, u64* left, u32* conn, u32* cflag) {
     u64 x = (u64)blockIdx.x * blockDim.x + threadIdx.x; if (x >= n) return;
-    Record r = in[x]; const u32 i = idOf[first + x]; right[i] = r.right; left[i] = r.left; conn[i] = r.conn;
-    (void)own; cflag[i] |= r.cflag;       // containment marks (economyGraph.cpp:735) are OR-ed, never overwritten: the local probe may have marked read i too
+    Record r = in[x]; const u64 p = first + x; right[p] = r.right; left[p] = r.left; conn[p] = r.conn;
+    cflag[p] |= r.cflag;                  // containment marks (economyGraph.cpp:735) are OR-ed, never overwritten: the local probe may have marked this read too
 }
 // containment flags travel as two byte planes (bit0 plane, bit1 plane) so that a MAX all-reduce is a bitwise OR
 __global__ void k_flags_export(u64 n, const u32* __restrict__ cflag, uint8_t* out) {
@@ -782,13 +785,13 @@ int dev_replace_cand_tail(Device* d, uint64_t keep, const void* src, uint64_t n,
 }
 int dev_export_records(Device* d, void* dst, uint64_t lo, uint64_t hi, std::string& err) {
     HIPCHK(hipSetDevice(d->ordinal));
-    if (hi > lo) hipLaunchKernelGGL(k_pack_records, dim3(grid_for(hi - lo, 256)), dim3(256), 0, d->stream, (u64)lo, (u64)hi, d->idOf, d->right, d->left, d->conn, d->cflag, (Record*)dst);
+    if (hi > lo) hipLaunchKernelGGL(k_pack_records, dim3(grid_for(hi - lo, 256)), dim3(256), 0, d->stream, (u64)lo, (u64)hi, d->right, d->left, d->conn, d->cflag, (Record*)dst);
     HIPCHK(hipStreamSynchronize(d->stream));
     return 0;
 }
 int dev_import_records(Device* d, const void* src, uint64_t first, uint64_t n, std::string& err) {
     HIPCHK(hipSetDevice(d->ordinal));
-    if (n) hipLaunchKernelGGL(k_unpack_records, dim3(grid_for(n, 256)), dim3(256), 0, d->stream, (u64)first, (u64)n, d->idOf, (const Record*)src, d->right, d->left, d->conn, d->cflag, false);
+    if (n) hipLaunchKernelGGL(k_unpack_records, dim3(grid_for(n, 256)), dim3(256), 0, d->stream, (u64)first, (u64)n, (const Record*)src, d->right, d->left, d->conn, d->cflag);
     HIPCHK(hipStreamSynchronize(d->stream));
     return 0;
 }
@@ -798,17 +801,17 @@ int dev_reciprocal(Device* d, uint64_t emit_lo, uint64_t emit_hi, uint64_t* n_ov
     const u64 N = d->N;
     HIPCHK(hipEventRecord(d->ev[0], d->stream));
     HIPCHK(hipMemsetAsync(d->d_counters, 0, 8 * sizeof(u64), d->stream));
-    HIPCHK(hipMemsetAsync(d->status, 0, N + 1, d->stream));
-    hipLaunchKernelGGL(k_recip_cond, dim3(grid_for(N, 256 * COND_PER_THREAD)), dim3(256), 0, d->stream, N, d->right, d->left, d->conn, d->cflag, d->status, d->d_counters);
+    // (records by position; the status goes out by position -- statusP, what the emit half and the hit-list kernels read -- and by id)
+    hipLaunchKernelGGL(k_recip_cond, dim3(grid_for(N, 256 * COND_PER_THREAD)), dim3(256), 0, d->stream, N, d->right, d->left, d->conn, d->cflag, d->idOf, d->status, d->statusP, d->d_counters);
     HIPCHK(hipEventRecord(d->ev[4], d->stream));
     if (d->diet && emit_hi > emit_lo) {                                     // the list is sized by a counting pass (capacity 0: nothing is written, the cursor counts)
-        hipLaunchKernelGGL(k_recip_emit, dim3(grid_for(emit_hi - emit_lo, 256 * EMIT_PER_THREAD)), dim3(256), 0, d->stream, N, d->reads, d->S, d->uniL, d->right, d->left, d->status, (EdgeCand*)nullptr, (u64)0, d->d_counters, (u64)emit_lo, (u64)emit_hi);
+        hipLaunchKernelGGL(k_recip_emit, dim3(grid_for(emit_hi - emit_lo, 256 * EMIT_PER_THREAD)), dim3(256), 0, d->stream, N, d->readsLoc, d->S, d->uniL, d->right, d->left, d->statusP, d->idOf, (EdgeCand*)nullptr, (u64)0, d->d_counters, (u64)emit_lo, (u64)emit_hi);
         u64 want = 0; HIPCHK(hipMemcpyAsync(&want, d->d_counters, sizeof want, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
         if (want + 1024 > d->cand_cap || !d->cand) { hipFree(d->cand); d->cand = nullptr; d->cand_cap = want + 1024; HIPCHK(hipMalloc(&d->cand, d->cand_cap * sizeof(EdgeCand))); }
         HIPCHK(hipMemsetAsync(d->d_counters, 0, sizeof(u64), d->stream));
     }
     if (emit_hi > emit_lo)
-        hipLaunchKernelGGL(k_recip_emit, dim3(grid_for(emit_hi - emit_lo, 256 * EMIT_PER_THREAD)), dim3(256), 0, d->stream, N, d->reads, d->S, d->uniL, d->right, d->left, d->status, d->cand, d->cand_cap, d->d_counters, (u64)emit_lo, (u64)emit_hi);
+        hipLaunchKernelGGL(k_recip_emit, dim3(grid_for(emit_hi - emit_lo, 256 * EMIT_PER_THREAD)), dim3(256), 0, d->stream, N, d->readsLoc, d->S, d->uniL, d->right, d->left, d->statusP, d->idOf, d->cand, d->cand_cap, d->d_counters, (u64)emit_lo, (u64)emit_hi);
     u64 c[8];
     HIPCHK(hipMemcpyAsync(c, d->d_counters, sizeof c, hipMemcpyDeviceToHost, d->stream));
     HIPCHK(hipEventRecord(d->ev[1], d->stream));
@@ -823,10 +826,17 @@ int dev_reciprocal(Device* d, uint64_t emit_lo, uint64_t emit_hi, uint64_t* n_ov
 int dev_download_initial(Device* d, uint64_t* right, uint64_t* left, uint8_t* status, uint32_t* conn, std::string& err) {
     HIPCHK(hipSetDevice(d->ordinal));
     const u64 N = d->N;
-    if (right) HIPCHK(hipMemcpy(right, d->right, (N + 1) * sizeof(u64), hipMemcpyDeviceToHost));
-    if (left) HIPCHK(hipMemcpy(left, d->left, (N + 1) * sizeof(u64), hipMemcpyDeviceToHost));
+    if (right || left || conn) {                                           // the C ABI's arrays are indexed by id and name neighbours by id (economyGraph.h:24-30)
+        u64* ri = nullptr; u64* li = nullptr; u32* ci = nullptr;
+        struct Free { u64*& a; u64*& b; u32*& c; ~Free() { hipFree(a); hipFree(b); hipFree(c); } } fr{ri, li, ci};
+        HIPCHK(hipMalloc(&ri, (N + 1) * sizeof(u64))); HIPCHK(hipMalloc(&li, (N + 1) * sizeof(u64))); HIPCHK(hipMalloc(&ci, (N + 1) * sizeof(u32)));
+        hipLaunchKernelGGL(k_records_to_ids, dim3(grid_for(N + 1, 256)), dim3(256), 0, d->stream, (u64)N, d->idOf, d->right, d->left, d->conn, ri, li, ci);
+        HIPCHK(hipGetLastError()); HIPCHK(hipStreamSynchronize(d->stream));
+        if (right) HIPCHK(hipMemcpy(right, ri, (N + 1) * sizeof(u64), hipMemcpyDeviceToHost));
+        if (left) HIPCHK(hipMemcpy(left, li, (N + 1) * sizeof(u64), hipMemcpyDeviceToHost));
+        if (conn) HIPCHK(hipMemcpy(conn, ci, (N + 1) * sizeof(u32), hipMemcpyDeviceToHost));
+    }
     if (status) HIPCHK(hipMemcpy(status, d->status, N + 1, hipMemcpyDeviceToHost));
-    if (conn) HIPCHK(hipMemcpy(conn, d->conn, (N + 1) * sizeof(u32), hipMemcpyDeviceToHost));
     return 0;
 }
 int dev_download_status(Device* d, std::vector<uint8_t>& status, std::string& err) {
@@ -837,12 +847,12 @@ int dev_download_status(Device* d, std::vector<uint8_t>& status, std::string& er
 }
 
 int dev_unresolved_ids(Device* d, std::vector<uint32_t>& ids, std::string& err);
-int dev_unresolved_hits(Device* d, std::vector<Hit>& hits, uint64_t* n_unresolved, std::string& err) {
+int dev_unresolved_hits(Device* d, std::vector<Hit>& hits, uint64_t* n_unresolved, std::string& err, std::vector<uint32_t>* ids_out) {
     HIPCHK(hipSetDevice(d->ordinal));
     HIPCHK(hipEventRecord(d->ev[0], d->stream));
     std::vector<uint32_t> ids; int rc = dev_unresolved_ids(d, ids, err); if (rc) return rc;
     u64 nun = ids.size();
-    *n_unresolved = nun; hits.clear();
+    *n_unresolved = nun; hits.clear(); if (ids_out) *ids_out = ids;
     if (nun == 0) return 0;
     u64 cap = std::max<u64>(1 << 16, nun * 80);
     for (int attempt = 0; attempt < 4; attempt++) {
@@ -1091,7 +1101,6 @@ int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved
     WS(hitcount, u32, WS_RA_CUR, N + 2);
     u32* locDev = nullptr;                                                       // ranked form: read id -> 1-based position in the locality order
     {
-        { int rc = refresh_status_by_pos(d, err); if (rc) return rc; }
         const u32* order = d->idOf + 1;                                            // ids in locality order (positions 1..N)
         if (ranked) locDev = d->posOf;
         if (ranked || shareWorld > 1) {                                            // (several ranks cut the SAME list into shares: it must not depend on the order of atomics)
@@ -1316,10 +1325,34 @@ int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved
 // candidates that touch an unresolved read or one of its neighbours (their adjacency lists are what
 // markTransitiveEdge reads, economyGraph.cpp:643-679); candidates owned by unresolved reads are flagged
 // as dropped on the device: the replay re-emits the survivors.
-int dev_collect_reduce_edges(Device* d, std::vector<EdgeCand>& out, std::string& err) {
+int dev_collect_reduce_edges(Device* d, const std::vector<uint32_t>& unresolved, std::vector<EdgeCand>& out, std::string& err) {
     HIPCHK(hipSetDevice(d->ordinal));
     out.clear(); const u64 n = d->n_cand; if (n == 0) return 0;
     EdgeCand* buf = nullptr; u64 cap = 1 << 16;
+    const u32 nUn = (u32)std::min<size_t>(unresolved.size(), 1u << 30);
+    if (nUn && nUn <= FEW_MAX / 3 && !getenv("SAGE2OV_TEST_GENERAL_COLLECT")) {
+        // a handful of unresolved reads (see k_red_collect_few): the short list = these reads + their two extension partners, found from their records
+        WS(dIds, u32, WS_IDS, 4 * (u64)FEW_MAX); WS(dRec, u64, WS_NEED, 2 * (u64)nUn + 2);
+        u32* dNeed = dIds + FEW_MAX;
+        HIPCHK(hipMemcpyAsync(dIds, unresolved.data(), nUn * sizeof(u32), hipMemcpyHostToDevice, d->stream));
+        hipLaunchKernelGGL(k_gather_records, dim3(grid_for(nUn, 256)), dim3(256), 0, d->stream, dIds, nUn, d->posOf, d->idOf, d->right, d->left, dRec);
+        std::vector<u64> rec(2 * (size_t)nUn); HIPCHK(hipMemcpyAsync(rec.data(), dRec, rec.size() * sizeof(u64), hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
+        std::vector<u32> need(unresolved.begin(), unresolved.begin() + nUn);
+        for (u64 r : rec) { const u32 id = (u32)(r & ((1ull << 40) - 1)); if (id) need.push_back(id); }
+        std::sort(need.begin(), need.end()); need.erase(std::unique(need.begin(), need.end()), need.end());
+        HIPCHK(hipMemcpyAsync(dNeed, need.data(), need.size() * sizeof(u32), hipMemcpyHostToDevice, d->stream));
+        const unsigned blocks = (unsigned)std::min<u64>(grid_for(n, 256), 256ull * 8);
+        // (every candidate that touches a read of the short list was emitted by a read of the list or by a partner of one: at most 2 per read and partner)
+        cap = 2 * (u64)need.size() * 3 + 64; { WS(nb_, EdgeCand, WS_NEAR, cap); buf = nb_; }
+        HIPCHK(hipMemsetAsync(d->d_counters + 5, 0, sizeof(u64), d->stream));
+        hipLaunchKernelGGL(k_red_collect_few, dim3(blocks), dim3(256), 0, d->stream, d->cand, (u64)n, dNeed, (u32)need.size(), dIds, nUn, buf, cap, d->d_counters + 5);
+        HIPCHK(hipGetLastError());
+        u64 cnt = 0; HIPCHK(hipMemcpyAsync(&cnt, d->d_counters + 5, sizeof cnt, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
+        if (cnt <= cap) {                                                  // (else: the general form below -- the 0x80 flags are idempotent)
+            out.resize(cnt); if (cnt) HIPCHK(hipMemcpy(out.data(), buf, cnt * sizeof(EdgeCand), hipMemcpyDeviceToHost));
+            return 0;
+        }
+    }
     WS(need, uint8_t, WS_NEED, d->N + 1); HIPCHK(hipMemsetAsync(need, 0, d->N + 1, d->stream));
     hipLaunchKernelGGL(k_red_mark, dim3(grid_for(n, 256)), dim3(256), 0, d->stream, d->cand, (u64)n, d->status, need);
     // first a dry count (cap 0 keeps the flagging idempotent), then the real collection
@@ -1393,7 +1426,9 @@ int dev_debug_all_hits(Device* d, std::vector<Hit>& hits, std::string& err) {
     if (!rc) { HIPCHK(hipMemcpyAsync(&nh, d->d_counters + 4, sizeof nh, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream)); }
     if (!rc && nh > cap) { err = "debug hit buffer too small"; rc = SAGE2OV_ERR_LIMIT; }
     if (!rc) { hits.resize(nh); if (nh) HIPCHK(hipMemcpy(hits.data(), dh, nh * sizeof(Hit), hipMemcpyDeviceToHost)); }
-    HIPCHK(hipMemcpyAsync(d->status, saved, N + 1, hipMemcpyDeviceToDevice, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
+    HIPCHK(hipMemcpyAsync(d->status, saved, N + 1, hipMemcpyDeviceToDevice, d->stream));
+    { int rc2 = refresh_status_by_pos(d, err); if (!rc) rc = rc2; }      // (statusP is what the reciprocal pass left again)
+    HIPCHK(hipStreamSynchronize(d->stream));
     hipFree(saved); hipFree(dh);
     return rc;
 }
@@ -1452,22 +1487,23 @@ int dev_convert(Device* d, uint64_t* n_final, std::string& err) {
     d->final_edges = nullptr; d->n_final = 0;
     HIPCHK(hipEventRecord(d->ev[0], d->stream));
     if (n) {
-        if (n >= (1ull << 32)) { err = "too many edge candidates"; return SAGE2OV_ERR_LIMIT; }
-        WS(deg, u32, WS_DEG, N + 2); WS(offs, u32, WS_OFFS, N + 2); WS(cursor, u32, WS_CURSOR, N + 2);
-        WS(keys, u64, WS_KEYS, n); WS(keep, u32, WS_KEEP, n); WS(pos, u32, WS_POS, n); WS(owner, u32, WS_OWNER, n);
-        HIPCHK(hipMemsetAsync(deg, 0, (N + 2) * sizeof(u32), d->stream)); HIPCHK(hipMemsetAsync(cursor, 0, (N + 2) * sizeof(u32), d->stream));
-        hipLaunchKernelGGL(k_conv_degree, dim3(grid_for(n, 256)), dim3(256), 0, d->stream, d->cand, (u64)n, deg);
-        u64 tot = 0; int rc = scan_u32(d, deg, N + 1, offs, &tot, err); if (rc) return rc;
-        hipLaunchKernelGGL(k_conv_fill, dim3(grid_for(n, 256)), dim3(256), 0, d->stream, d->cand, (u64)n, offs, cursor, keys);
-        hipLaunchKernelGGL(k_conv_sort, dim3(grid_for(N + 1, 256)), dim3(256), 0, d->stream, (u64)N, offs, deg, keys, keep);
-        hipLaunchKernelGGL(k_conv_owner, dim3(grid_for(N + 1, 256)), dim3(256), 0, d->stream, (u64)N, offs, deg, owner);
-        // `tot` = candidates still alive (dropped ones were never filled in): only keys[0..tot) are defined
-        u64 nf = 0;
-        if (tot) {
-            rc = scan_u32(d, keep, tot, pos, &nf, err); if (rc) return rc;
-            { WS(fe, FinalEdge, WS_FINAL, std::max<u64>(1, nf)); d->final_edges = fe; }
-            hipLaunchKernelGGL(k_conv_emit, dim3(grid_for(tot, 256)), dim3(256), 0, d->stream, (u64)tot, keys, keep, pos, owner, d->reads, d->S, d->uniL, d->final_edges);
-        }
+        if (n >= (1ull << 32) - PT_TILE) { err = "too many edge candidates"; return SAGE2OV_ERR_LIMIT; }
+        // Round 3: the candidates arrive in POSITION order of their emitters (their `from` ids are random): a stable LSD radix sort by `from`
+        // (kernels_partition.inc, <= 9 bits per pass; the candidate list itself is only read) makes every read's list contiguous without an atomic --
+        // the counting form this replaces (two atomics per candidate on per-read counters) took 5.4 ms at BASELINE configs[2], 3.4 when the
+        // candidates still came in id order.
+        PtBufs B; B.W = 4; B.src0 = (const u32*)d->cand;
+        { WS(a, u32, WS_PT_K0, 4 * (n + 4)); B.E[0] = a; } { WS(a, u32, WS_PT_K1, 4 * (n + 4)); B.E[1] = a; }
+        const u32 ntiles = (u32)((n + PT_TILE - 1) / PT_TILE);
+        WS(cnt, u32, WS_PT_CNT, (u64)PT_NB_MAX * std::max<u32>(ntiles, 1) + 2); WS(base, u32, WS_PT_BASE, (u64)PT_NB_MAX * std::max<u32>(ntiles, 1) + 2);
+        WS(keys, u64, WS_KEYS, n); WS(keep, u32, WS_KEEP, n); WS(pos, u32, WS_POS, n);
+        int cur = 0; int rc = partition_by_window(d, B, 0, (u32)n, 0, N + 2, false, cnt, base, nullptr, &cur, err); if (rc) return rc;
+        const EdgeCand* sorted = (const EdgeCand*)B.E[cur];
+        hipLaunchKernelGGL(k_conv_group, dim3(grid_for(n, 256)), dim3(256), 0, d->stream, sorted, (u64)n, keys, keep);
+        u64 nf = 0; rc = scan_u32(d, keep, n, pos, &nf, err); if (rc) return rc;
+        { WS(fe, FinalEdge, WS_FINAL, std::max<u64>(1, nf)); d->final_edges = fe; }
+        hipLaunchKernelGGL(k_conv_emit, dim3(grid_for(n, 256)), dim3(256), 0, d->stream, (u64)n, keys, keep, pos, sorted, d->reads, d->S, d->uniL, d->final_edges);
+        HIPCHK(hipGetLastError());
         d->n_final = nf;
         HIPCHK(hipStreamSynchronize(d->stream));
     }
@@ -1475,7 +1511,7 @@ int dev_convert(Device* d, uint64_t* n_final, std::string& err) {
     HIPCHK(hipStreamSynchronize(d->stream));
     float ms = 0; hipEventElapsedTime(&ms, d->ev[0], d->ev[1]); d->tm.convert_ms += ms;
     mem_sample(d);
-    if (d->diet) for (int id : {WS_DEG, WS_OFFS, WS_CURSOR, WS_KEYS, WS_KEEP, WS_POS, WS_OWNER, WS_PARTIAL}) ws_free(d, id);
+    if (d->diet) for (int id : {WS_PT_K0, WS_PT_K1, WS_PT_CNT, WS_PT_BASE, WS_KEYS, WS_KEEP, WS_POS, WS_PARTIAL}) ws_free(d, id);
     *n_final = d->n_final;
     return 0;
 }

@@ -929,12 +929,12 @@ int sage2ov_overlap_reduce(sage2ov_ctx* c) {
     std::vector<Hit> hits; uint64_t nun = 0;
     const bool timing = getenv("SAGE2OV_TIMING") != nullptr; auto tp = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) { if (!timing) return; auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[reduce/host] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(t - tp).count()); tp = t; };
-    int rc = dev_unresolved_hits(c->dev, hits, &nun, c->err); if (rc) return rc;
+    std::vector<uint32_t> ids;
+    int rc = dev_unresolved_hits(c->dev, hits, &nun, c->err, &ids); if (rc) return rc;
     lap("hit lists (device + download)");
     c->ostats.unresolved_hits = hits.size(); c->ostats.edges_inserted = 0; c->ostats.transitive_removed = 0;
     if (nun) {
-        std::vector<uint32_t> ids; rc = dev_unresolved_ids(c->dev, ids, c->err); if (rc) return rc;
-        std::vector<EdgeCand> near; rc = dev_collect_reduce_edges(c->dev, near, c->err); if (rc) return rc;
+        std::vector<EdgeCand> near; rc = dev_collect_reduce_edges(c->dev, ids, near, c->err); if (rc) return rc;
         lap("ids + nearby candidates");
         __gnu_parallel::sort(hits.begin(), hits.end(), [](const Hit& a, const Hit& b) { return a.from != b.from ? a.from < b.from : a.seq < b.seq; }, __gnu_parallel::default_parallel_tag(io_threads(c)));
         lap("sort hits");

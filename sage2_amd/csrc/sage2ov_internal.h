@@ -59,10 +59,10 @@ int dev_set_cands(Device* d, const void* dev_src, uint64_t n, std::string& err);
 void dev_set_probe_share(Device* d, double share);    // share of the reads this context probes (1 / world): decides whether the minimiser groups pay
 int dev_download_initial(Device* d, uint64_t* right, uint64_t* left, uint8_t* status, uint32_t* conn, std::string& err);
 // directional hit lists of status-0 reads (economyGraph.cpp:591-633), sorted by (from, seq)
-int dev_unresolved_hits(Device* d, std::vector<Hit>& hits, uint64_t* n_unresolved, std::string& err);
+int dev_unresolved_hits(Device* d, std::vector<Hit>& hits, uint64_t* n_unresolved, std::string& err, std::vector<uint32_t>* ids_out = nullptr);   // ids_out: the unresolved ids, ascending
 int dev_download_status(Device* d, std::vector<uint8_t>& status, std::string& err);
 int dev_unresolved_ids(Device* d, std::vector<uint32_t>& ids, std::string& err);          // ascending
-int dev_collect_reduce_edges(Device* d, std::vector<EdgeCand>& out, std::string& err);
+int dev_collect_reduce_edges(Device* d, const std::vector<uint32_t>& unresolved, std::vector<EdgeCand>& out, std::string& err);
 // ASCII input of step 1 (sage2ov_reads_add_ascii): raw bases + offsets in, filter / pack / canonical orientation on the device; the counters come back
 struct OrgAscii { const char* bases; uint64_t nbytes; const uint64_t* off; uint64_t n_in; uint64_t good = 0, total_bp = 0, small = 0; int maxL = 0, minL = 0, S = 0; };
 int dev_organize_reads(Device* d, const uint64_t* pool, uint64_t pool_words, const uint64_t* off, const uint16_t* len, uint64_t n, int S, int minL, int maxL, int k,

@@ -55,7 +55,8 @@ struct Rank {
     int allgather(const void* send, void* recv, size_t bytes) {
         if (!S.shareGpu) { if (ncclAllGather(send, recv, bytes, ncclUint8, S.comms[r], st) != ncclSuccess) return fail("ncclAllGather"); return hipStreamSynchronize(st) == hipSuccess ? 0 : fail("stream sync"); }
         S.sendPtr[r] = send; BAR();
-        for (int q = 0; q < S.G; q++) if (bytes && hipMemcpy((char*)recv + (size_t)q * bytes, S.sendPtr[q], bytes, hipMemcpyDeviceToDevice) != hipSuccess) return fail("device copy");
+        for (int q = 0; q < S.G; q++) if (bytes && hipMemcpyAsync((char*)recv + (size_t)q * bytes, S.sendPtr[q], bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail("device copy");
+        if (hipStreamSynchronize(st) != hipSuccess) return fail("stream sync");       // (a device-to-device hipMemcpy may return before it has run, and nothing orders the null stream with the library's stream)
         BAR(); return 0;
     }
     int allreduce_max_bytes(void* buf, size_t bytes) {          // in place
@@ -102,7 +103,8 @@ struct Rank {
         DevBuf send, recv, planes, bucket, padded, gathered, all, scratch;
         // 1. records
         if (send.need((maxShard ? maxShard : 1) * 24) || recv.need((size_t)S.G * (maxShard ? maxShard : 1) * 24)) return fail("hipMalloc");
-        if (hipMemset(send.p, 0, (maxShard ? maxShard : 1) * 24) != hipSuccess) return fail("memset");
+        // (on the context's own stream: a hipMemset on the null stream is not ordered with the library's non-blocking stream -- it could land on top of the exported records)
+        if (hipMemsetAsync(send.p, 0, (maxShard ? maxShard : 1) * 24, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return fail("memset");
         S2(sage2ov_shard_export_records(ctx, send.p, maxShard));
         // 2. containment planes (exported before other ranks' records arrive; the import ORs the flags a record carries)
         uint64_t fb = 0; S2(sage2ov_shard_flags_bytes(ctx, &fb));
