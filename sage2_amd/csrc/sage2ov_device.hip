@@ -1058,6 +1058,11 @@ static void explore_order_impl(const std::vector<u32>& pos, const std::vector<co
     for (u32 q : pos) rank[q] &= XO_RK;
     rankv.assign(rank, rank + N + 2);
 }
+// (Round 3, measured and dropped: the same walk on bit maps -- lists kept as {64-position word of the order, member mask} segments, 5.6 per list, "explored" / "marked" one
+// bit per position, a scan = `mask & ~explored[word]` resp. `mask & explored[word] & ~marked[word]` per segment, set bits resolved against the list only when order or
+// kind matter.  Exact (0 of 8.7 M ranks differ on the 10 M-read repeat data set) and 1.28 -> 0.9-1.0 s for the walk itself, but the segments take 115 ms to build on 16
+// host threads and the reduce phase as a whole came out level (1.80-1.84 s against 1.81-1.99 s): the walk is a chain of ~1 event per pop with ~100 cycles of scattered work
+// each, not a scan-bound loop.  DESIGN 5.5.)
 static void explore_order(const std::vector<u32>& pos, const std::vector<const u32*>& lists, const std::vector<u32>& lenp, const std::vector<uint8_t>& hasCand,
                           u64 N, const std::vector<u32>& startOrder, std::vector<u32>& rank) {
 #if defined(__x86_64__)
