@@ -588,7 +588,31 @@ static bool launch_fast_any(Device* d, ProbeArgs& A, unsigned blocks) {
     else return false;
     return true;
 }
-static unsigned fast_blocks(u64 n) { return (unsigned)std::min<u64>((n + FAST_CHUNK - 1) / FAST_CHUNK, 256ull * 16); }
+// The grid of the fast kernel.  Every block walks its chunks in a fixed round-robin order and is resident until its slowest wave is done, so the grid's granularity
+// decides how long CUs idle at the end of the launch.  Measured at BASELINE configs[2] (round 3, uniform grids, blocks per CU -> kernel ms): 4 -> 92.2, 8 -> 90.8, 16 -> 89.6
+// (rounds 1-2), 32 -> 88.7, 64 -> 88.0, 256 -> 88.4, one chunk per block -> 93.2 (a block's start and drain cost ~5 us).  Hence a TAPERED grid: up to three phases of 4096
+// blocks that take 3/4 of what is left each (60 / 15 / ... rounds at configs[2]), then the rest in blocks of a few chunks -- the blocks the hardware dispatches last are short.
+// Launches that write hits out reserve a 2048-slot chunk of the hit buffer per wave at a time: they keep one phase of 16 blocks per CU, or the buffer's slack quadruples.
+// SAGE2OV_FAST_BLOCKS_PER_CU=<n>: one uniform phase of n blocks per CU (diagnostic).
+static unsigned plan_fast_grid(ProbeArgs& A, u64 n, bool writesHits = false) {
+    static const int uniform = getenv("SAGE2OV_FAST_BLOCKS_PER_CU") ? std::max(1, atoi(getenv("SAGE2OV_FAST_BLOCKS_PER_CU"))) : 0;
+    memset(A.phase, 0, sizeof A.phase);
+    const u64 C = (n + FAST_CHUNK - 1) / FAST_CHUNK;
+    if (writesHits || uniform || C <= 4096ull * 8) {
+        const u64 nb = std::max<u64>(1, std::min<u64>(C, 256ull * (writesHits ? 16 : (uniform ? uniform : 16))));
+        A.phase[0][0] = 0; A.phase[0][1] = (u32)nb; A.phase[0][2] = (u32)((C + nb - 1) / nb); A.phase[0][3] = 0;
+        return (unsigned)nb;
+    }
+    u64 rem = C, chunk0 = 0, block0 = 0; int p = 0;
+    for (; p < 3 && rem > 4096ull * 8; p++) {
+        const u64 r = rem * 3 / 4 / 4096;
+        A.phase[p][0] = (u32)block0; A.phase[p][1] = 4096; A.phase[p][2] = (u32)r; A.phase[p][3] = (u32)chunk0;
+        block0 += 4096; chunk0 += 4096 * r; rem -= 4096 * r;
+    }
+    const u64 nb = std::min<u64>(rem, 8192);
+    A.phase[p][0] = (u32)block0; A.phase[p][1] = (u32)nb; A.phase[p][2] = (u32)((rem + nb - 1) / nb); A.phase[p][3] = (u32)chunk0;
+    return (unsigned)(block0 + nb);
+}
 
 void dev_set_probe_share(Device* d, double share) { d->probeShare = share; }
 
@@ -659,18 +683,17 @@ int dev_probe(Device* d, uint64_t lo, uint64_t hi, std::string& err) {
         };
         if (nsample && nsample < nreads) {
             ProbeArgs As = A; As.hi = lo + nsample;
-            int rc = timed([&] { launched = launch_fast_any<0, 0>(d, As, fast_blocks(nsample)); }); if (rc) return rc;
+            int rc = timed([&] { launched = launch_fast_any<0, 0>(d, As, plan_fast_grid(As, nsample)); }); if (rc) return rc;
             if (launched) {
                 anyListed = true;
                 tailKernel = nslow * 2 > nsample ? 2 : (nslow * 32 > nsample ? 1 : 0);   // listed: more than half -> state machine for every read; more than 3 % -> kernel that carries it
-                ProbeArgs Ar = A; Ar.lo = lo + nsample; const unsigned nb = fast_blocks(nreads - nsample);
+                ProbeArgs Ar = A; Ar.lo = lo + nsample; const unsigned nb = plan_fast_grid(Ar, nreads - nsample, tailKernel == 2);
                 bool armed = false; { int rca = arm_prehits(Ar, nreads - nsample, nb, armed); if (rca) return rca; }
                 rc = timed([&] { if (tailKernel == 2) launch_fast_any<0, 2>(d, Ar, nb); else if (tailKernel == 1) launch_fast_any<0, 1>(d, Ar, nb); else launch_fast_any<0, 0>(d, Ar, nb); }); if (rc) return rc;
                 if (armed) { int rca = close_prehits(); if (rca) return rca; }
             }
         } else {
-            const unsigned nb = fast_blocks(nreads);
-            ProbeArgs Aw = A; bool armed = false; { int rca = arm_prehits(Aw, nreads, nb, armed); if (rca) return rca; }
+            ProbeArgs Aw = A; const unsigned nb = plan_fast_grid(Aw, nreads, tailKernel == 2); bool armed = false; { int rca = arm_prehits(Aw, nreads, nb, armed); if (rca) return rca; }
             int rc = timed([&] { launched = tailKernel == 2 ? launch_fast_any<0, 2>(d, Aw, nb) : (tailKernel == 1 ? launch_fast_any<0, 1>(d, Aw, nb) : launch_fast_any<0, 0>(d, Aw, nb)); }); if (rc) return rc;
             if (armed && launched) { int rca = close_prehits(); if (rca) return rca; }
         }
@@ -689,7 +712,7 @@ int dev_probe(Device* d, uint64_t lo, uint64_t hi, std::string& err) {
             B.stamps = A.stamps;
 #endif
             const u64 nl = nslow;
-            int rc = timed([&] { launch_fast_any<0, 1>(d, B, fast_blocks(nl)); }); if (rc) return rc;
+            const unsigned nbl = plan_fast_grid(B, nl); int rc = timed([&] { launch_fast_any<0, 1>(d, B, nbl); }); if (rc) return rc;
             list = slow2;
         }
         d->tm.probe_kernel_ms += kms; d->tm.probe_launches++;
@@ -1136,7 +1159,7 @@ int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved
             if (fc[1]) {                                                              // unresolved reads without written hits: the hit-list kernel over their positions, appending
                 u64 c3[3] = {used, 0, 0}; HIPCHK(hipMemcpyAsync(d->d_counters + 4, c3, sizeof c3, hipMemcpyHostToDevice, d->stream));
                 ProbeArgs A = base_args(d); A.ids = noneList; A.n_ids = fc[1]; A.hits = dh; A.hits_cap = pcap; A.hitcount = hitcount; A.slow = slow; A.slow_cap = N + 1;
-                if (launch_fast_any<1, 0>(d, A, fast_blocks(fc[1]))) {
+                if (launch_fast_any<1, 0>(d, A, plan_fast_grid(A, fc[1], true))) {
                     HIPCHK(hipGetLastError());
                     HIPCHK(hipMemcpyAsync(c3, d->d_counters + 4, sizeof c3, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
                     if (c3[0] > pcap) ok = false;
