@@ -594,22 +594,25 @@ static bool launch_fast_any(Device* d, ProbeArgs& A, unsigned blocks) {
 // blocks that take 3/4 of what is left each (60 / 15 / ... rounds at configs[2]), then the rest in blocks of a few chunks -- the blocks the hardware dispatches last are short.
 // Launches that write hits out reserve a 2048-slot chunk of the hit buffer per wave at a time: they keep one phase of 16 blocks per CU, or the buffer's slack quadruples.
 // SAGE2OV_FAST_BLOCKS_PER_CU=<n>: one uniform phase of n blocks per CU (diagnostic).
+// SAGE2OV_FAST_BLOCKS_PER_CU=<n>: one uniform phase of n blocks per CU (diagnostic); SAGE2OV_TEST_PHASE_BLOCKS=<b>: phases of b blocks instead of 4096 (tests: several
+// phases on a few thousand reads).
 static unsigned plan_fast_grid(ProbeArgs& A, u64 n, bool writesHits = false) {
-    static const int uniform = getenv("SAGE2OV_FAST_BLOCKS_PER_CU") ? std::max(1, atoi(getenv("SAGE2OV_FAST_BLOCKS_PER_CU"))) : 0;
+    const char* eu = getenv("SAGE2OV_FAST_BLOCKS_PER_CU"); const int uniform = eu ? std::max(1, atoi(eu)) : 0;
+    const char* ep = getenv("SAGE2OV_TEST_PHASE_BLOCKS"); const u64 PB = ep ? (u64)std::max(1, atoi(ep)) : 4096;
     memset(A.phase, 0, sizeof A.phase);
     const u64 C = (n + FAST_CHUNK - 1) / FAST_CHUNK;
-    if (writesHits || uniform || C <= 4096ull * 8) {
+    if (writesHits || uniform || C <= PB * 8) {
         const u64 nb = std::max<u64>(1, std::min<u64>(C, 256ull * (writesHits ? 16 : (uniform ? uniform : 16))));
         A.phase[0][0] = 0; A.phase[0][1] = (u32)nb; A.phase[0][2] = (u32)((C + nb - 1) / nb); A.phase[0][3] = 0;
         return (unsigned)nb;
     }
     u64 rem = C, chunk0 = 0, block0 = 0; int p = 0;
-    for (; p < 3 && rem > 4096ull * 8; p++) {
-        const u64 r = rem * 3 / 4 / 4096;
-        A.phase[p][0] = (u32)block0; A.phase[p][1] = 4096; A.phase[p][2] = (u32)r; A.phase[p][3] = (u32)chunk0;
-        block0 += 4096; chunk0 += 4096 * r; rem -= 4096 * r;
+    for (; p < 3 && rem > PB * 8; p++) {
+        const u64 r = rem * 3 / 4 / PB;
+        A.phase[p][0] = (u32)block0; A.phase[p][1] = (u32)PB; A.phase[p][2] = (u32)r; A.phase[p][3] = (u32)chunk0;
+        block0 += PB; chunk0 += PB * r; rem -= PB * r;
     }
-    const u64 nb = std::min<u64>(rem, 8192);
+    const u64 nb = std::min<u64>(rem, 2 * PB);
     A.phase[p][0] = (u32)block0; A.phase[p][1] = (u32)nb; A.phase[p][2] = (u32)((rem + nb - 1) / nb); A.phase[p][3] = (u32)chunk0;
     return (unsigned)(block0 + nb);
 }

@@ -854,6 +854,25 @@ def test_probe_kernel_choice_is_exact(pd, k, mode, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("phase_blocks", ["1", "3", "7"])
+@pytest.mark.parametrize("pd,k", [
+    (dict(seed=81, genome_len=60000, n_reads=20000, read_len=150, err_ppm=0), 40),
+    (dict(seed=82, genome_len=45000, n_reads=15000, read_len=150, read_len_min=100, err_ppm=700), 33),
+])
+def test_tapered_grid_of_the_fast_kernel_is_exact(pd, k, phase_blocks, monkeypatch):
+    """Big launches of the fast probe kernel run a TAPERED grid (plan_fast_grid: up to three phases of 4096 blocks that take 3/4 of the remaining chunks each, then short
+    blocks -- the launch has no long tail); SAGE2OV_TEST_PHASE_BLOCKS shrinks a phase to a few blocks so that a few thousand reads walk through all four phases.
+    Every chunk must be visited exactly once: the oracle's records, counters and edges."""
+    monkeypatch.setenv("SAGE2OV_TEST_PHASE_BLOCKS", phase_blocks)
+    monkeypatch.setenv("SAGE2OV_PROBE_TAIL", "1")                                   # (one launch over the whole range with the kernel that settles inconsistent reads itself)
+    bases, off = fx.make_reads(pd)
+    m = dict(k=k)
+    g, o = run_gpu(m, bases, off), run_oracle(m, bases, off)
+    assert_equals_oracle(g, o)
+    g.close(); o.close()
+
+
+@pytest.mark.gpu
 def test_reads_beyond_the_longest_layout_are_refused():
     """1018 bases is the limit of the 32-word layout; a longer read is reported by the organiser (ASCII and device-pack path alike), not truncated."""
     pd = dict(seed=5, genome_len=20000, n_reads=300, read_len=1019, read_len_min=900)
