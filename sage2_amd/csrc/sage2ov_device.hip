@@ -448,7 +448,8 @@ int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t
         // one word per SURPLUS tuple of a heavy window (more than 3072 tuples where the mean is 2048: keys in thousands of reads); small inputs get the
         // worst case (every tuple in one window), big ones an eighth of it
         { const u64 whCap = n <= (64u << 20) ? nAlloc : nAlloc / 8; WS(whs, u64, WS_WHERE, whCap); A.wh = whs; A.wh_cap = whCap; }
-        hipLaunchKernelGGL(k_ix_window, dim3((unsigned)std::min<u64>(nW, 256ull * 6)), dim3(256), 0, d->stream, A);      // persistent: two rounds of 3 workgroups per CU, each with ONE pair of statistics atomics
+        static const u64 ixPerCu = getenv("SAGE2OV_IXW_GRID_PER_CU") ? std::max(1, atoi(getenv("SAGE2OV_IXW_GRID_PER_CU"))) : 6;
+        hipLaunchKernelGGL(k_ix_window, dim3((unsigned)std::min<u64>(nW, 256ull * ixPerCu)), dim3(256), 0, d->stream, A);      // persistent: two rounds of 3 workgroups per CU, each with ONE pair of statistics atomics
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(c, d->d_counters + 8, sizeof c, hipMemcpyDeviceToHost, d->stream));
         u64 c9 = 0; HIPCHK(hipMemcpyAsync(&c9, d->d_counters + 8 + 9, sizeof c9, hipMemcpyDeviceToHost, d->stream));
@@ -474,7 +475,8 @@ int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t
                 lap("partition by group window");
                 MiWinArgs MA; MA.G = G.E[gcur]; MA.gOff = gOff; MA.gW = (u32)gW; MA.tlBits = tlBits; MA.mi1 = mi1; MA.krec = krec; MA.counters = d->d_counters + 8; MA.wh = A.wh; MA.wh_cap = A.wh_cap;
                 HIPCHK(hipMemsetAsync(d->d_counters + 8 + 9, 0, sizeof(u64), d->stream));                  // (the scratch cursor starts over)
-                hipLaunchKernelGGL(k_mi_window, dim3((unsigned)std::min<u64>(gW, 256ull * 8)), dim3(256), 0, d->stream, MA);
+                static const u64 miPerCu = getenv("SAGE2OV_MIW_GRID_PER_CU") ? std::max(1, atoi(getenv("SAGE2OV_MIW_GRID_PER_CU"))) : 8;
+                hipLaunchKernelGGL(k_mi_window, dim3((unsigned)std::min<u64>(gW, 256ull * miPerCu)), dim3(256), 0, d->stream, MA);
                 // the probe scan may run past the last group: empty records behind ALL records
                 u64 mc[3];
                 HIPCHK(hipMemcpyAsync(mc, d->d_counters + 8 + 5, sizeof mc, hipMemcpyDeviceToHost, d->stream));
@@ -602,7 +604,8 @@ static unsigned plan_fast_grid(ProbeArgs& A, u64 n, bool writesHits = false) {
     memset(A.phase, 0, sizeof A.phase);
     const u64 C = (n + FAST_CHUNK - 1) / FAST_CHUNK;
     if (writesHits || uniform || C <= PB * 8) {
-        const u64 nb = std::max<u64>(1, std::min<u64>(C, 256ull * (writesHits ? 16 : (uniform ? uniform : 16))));
+        const char* eh = getenv("SAGE2OV_FAST_HITS_BLOCKS_PER_CU"); const int hitsPerCu = eh ? std::max(1, atoi(eh)) : 16;
+        const u64 nb = std::max<u64>(1, std::min<u64>(C, 256ull * (writesHits ? hitsPerCu : (uniform ? uniform : 16))));
         A.phase[0][0] = 0; A.phase[0][1] = (u32)nb; A.phase[0][2] = (u32)((C + nb - 1) / nb); A.phase[0][3] = 0;
         return (unsigned)nb;
     }
@@ -1307,7 +1310,9 @@ int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved
     const u64 wlo = shareWorld > 1 ? nun * shareRank / shareWorld : 0, whi = shareWorld > 1 ? nun * (shareRank + 1) / shareWorld : nun;
     const u32* const idsAll = ids; ids = ids + wlo; const u64 nunAll = nun; nun = whi - wlo; (void)idsAll; (void)nunAll;
     WS(svn, u32, WS_NEED, nun + 2); WS(svoff, u32, WS_OWNER, nun + 2);
-    const unsigned gb = (unsigned)std::max<u64>(1, std::min<u64>((nun + 3) / 4, 256ull * 16));
+    // (the marks' grid: a wave per read, blocks walk the list round-robin; blocks per CU -> reduce phase at configs[1] + 0.1 % errors: 16 -> 69.5 ms, 64 -> 66.0, 256 -> 65.2, 1024 -> 65.2: the tail again)
+    static const u64 raPerCu = getenv("SAGE2OV_RA_GRID_PER_CU") ? std::max(1, atoi(getenv("SAGE2OV_RA_GRID_PER_CU"))) : 256;
+    const unsigned gb = (unsigned)std::max<u64>(1, std::min<u64>((nun + 3) / 4, 256ull * raPerCu));
     const u64 heavyCap = 1 << 16; WS(heavy, u32, WS_RA_HEAVY, heavyCap);
     WS(ent32, u32, WS_RA_ENT32, tot + 64); WS(split, u32, WS_RA_SPLIT, N + 2);
     hipLaunchKernelGGL(k_ra_pack32, dim3((unsigned)std::min<u64>((N + 4) / 4, 256ull * 64)), dim3(256), 0, d->stream, ent, offs, deg, (u64)N, ent32, split);
