@@ -356,9 +356,9 @@ static int partition_by_window(Device* d, PtBufs& B, int keyw, u32 n, int shiftW
             if (!(j == 0 && digit0Counted)) hipLaunchKernelGGL(k_pt_hist, dim3(ntiles), dim3(PT_THREADS), 0, d->stream, in + keyw, n, shift, mask, cnt, ntiles, (u32)B.W);
             int rc = scan_u32_async(d, cnt, (u64)(mask + 1) * ntiles, base, err); if (rc) return rc;
             const int o = (j == 0 && B.src0) ? 0 : (cur ^ 1);
-            if (B.W == 4 && keyw == 0) hipLaunchKernelGGL((k_pt_scatter<4, 0>), dim3(ntiles), dim3(PT_THREADS), 0, d->stream, in, n, shift, mask, base, ntiles, B.E[o]);
-            else if (B.W == 3 && keyw == 0) hipLaunchKernelGGL((k_pt_scatter<3, 0>), dim3(ntiles), dim3(PT_THREADS), 0, d->stream, in, n, shift, mask, base, ntiles, B.E[o]);
-            else if (B.W == 3 && keyw == 2) hipLaunchKernelGGL((k_pt_scatter<3, 2>), dim3(ntiles), dim3(PT_THREADS), 0, d->stream, in, n, shift, mask, base, ntiles, B.E[o]);
+            if (B.W == 4 && keyw == 0) hipLaunchKernelGGL((k_pt_scatter<4, 0>), dim3(ntiles), dim3(PT_SC_THREADS), 0, d->stream, in, n, shift, mask, base, ntiles, B.E[o]);
+            else if (B.W == 3 && keyw == 0) hipLaunchKernelGGL((k_pt_scatter<3, 0>), dim3(ntiles), dim3(PT_SC_THREADS), 0, d->stream, in, n, shift, mask, base, ntiles, B.E[o]);
+            else if (B.W == 3 && keyw == 2) hipLaunchKernelGGL((k_pt_scatter<3, 2>), dim3(ntiles), dim3(PT_SC_THREADS), 0, d->stream, in, n, shift, mask, base, ntiles, B.E[o]);
             else { err = "partition: unsupported tuple format"; return SAGE2OV_ERR_INTERNAL; }
             cur = o; in = B.E[o];
         }
