@@ -417,7 +417,7 @@ def main():
                          # memory-side bytes per launch (PMC, profiles/probe_traffic.json) over the live kernel time: what the kernel really pulls
                          "traffic_achieved": (traffic * share / (kern_ms * 1e-3) / 1e9) if (traffic and kern_ms > 0) else None,
                          "traffic_frac": (traffic * share / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and kern_ms > 0) else None,
-                         "limiter": "instruction issue (about 810 VALU + 480 scalar wave-instructions per read: the vector ALUs are 70 % busy at four waves per SIMD) and the one dependent table look-up per read that four waves cannot hide; memory-side traffic is below the algorithmic bytes since the locality-ordered store and window reuse (DESIGN.md 5.2)",
+                         "limiter": "instruction issue and latency together: about 830 VALU + 510 scalar wave-instructions per read at SIX waves per SIMD (round 3: 77 VGPRs; four waves left the vector ALUs 71 % busy with every wave waiting on its dependent table and candidate fetches); at this occupancy the candidates of 768 waves per XCD overflow its L2 and the memory-side traffic is x1.5 of the algorithmic bytes, served by the Infinity Cache (DESIGN.md 5.2)",
                          # a probe pass is up to three launches of the kernel: a sample of 1/128 of the range, the rest (the instantiation the sample picked), and the
                          # few reads the first two listed; kernel_ms and the bytes are those of the whole pass (sum over its launches)
                          "valu": valu,
