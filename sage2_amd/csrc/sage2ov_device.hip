@@ -571,7 +571,12 @@ static ProbeArgs base_args(Device* d) {
 }
 
 template <int S, int NW, int WPL, int WPB, int HITS, int TAIL>
-static void launch_fast(Device* d, ProbeArgs& A, unsigned blocks) { hipLaunchKernelGGL((k_probe_fast<S, NW, WPL, WPB, HITS, TAIL>), dim3(blocks), dim3(64 * WPB), 0, d->stream, A); }
+static void launch_fast(Device* d, ProbeArgs& A, unsigned blocks) {
+    if constexpr (HITS == 0 && TAIL == 0 && NW <= 10) {               // the clean-data form has an instantiation for read sets of ONE length (no per-candidate length registers)
+        if (A.uniL) { hipLaunchKernelGGL((k_probe_fast<S, NW, WPL, WPB, HITS, TAIL, true>), dim3(blocks), dim3(64 * WPB), 0, d->stream, A); return; }
+    }
+    hipLaunchKernelGGL((k_probe_fast<S, NW, WPL, WPB, HITS, TAIL, false>), dim3(blocks), dim3(64 * WPB), 0, d->stream, A);
+}
 // picks the instantiation for the resident reads; false: the 32-word layout (505 .. 1018 bases) has no fast kernel
 template <int HITS, int TAIL>
 static bool launch_fast_any(Device* d, ProbeArgs& A, unsigned blocks) {
