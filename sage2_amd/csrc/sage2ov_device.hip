@@ -1262,7 +1262,9 @@ int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved
             u64 totc = 0; { int rc = scan_u32(d, lenp + w0, nw, coff, &totc, err); if (rc) return rc; }
             WS(outc, u32, WS_RR_OUTC, totc + 64);
             hipLaunchKernelGGL(k_rr_compact, dim3((unsigned)std::min<u64>((nw + 3) / 4, 256ull * 16)), dim3(256), 0, d->stream, (u64)nw, offp, lenp + w0, coff, outp, locDev, outc);
+            lap("  potential lists: kernels");
             u32* hbuf = staging.get(totc); if (!hbuf) { err = "host staging buffer allocation failed"; return SAGE2OV_ERR_NOMEM; }
+            lap("  potential lists: staging buffer (2 MB pages, touched, registered)");
             HIPCHK(hipMemcpyAsync(hLen.data() + w0, lenp + w0, nw * sizeof(u32), hipMemcpyDeviceToHost, d->stream));
             if (totc) HIPCHK(hipMemcpyAsync(hbuf, outc, totc * sizeof(u32), hipMemcpyDeviceToHost, d->stream));
             HIPCHK(hipStreamSynchronize(d->stream));
@@ -1303,6 +1305,7 @@ int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved
           HIPCHK(hipStreamSynchronize(d->stream)); }
         if (nslots) hipLaunchKernelGGL(k_rr_degree_h, dim3(grid_for(nslots, 256)), dim3(256), 0, d->stream, dh, (u64)nslots, rankDev, deg, d->d_counters + 8);
     } else hipLaunchKernelGGL(k_ra_degree_h, dim3(grid_for(N + 1, 256)), dim3(256), 0, d->stream, hitcount, (u64)N, deg);
+    lap("  ranks to the device, degrees of the final lists");
     u64 tot = 0; { int rc = scan_u32(d, deg, N + 2, offs, &tot, err); if (rc) return rc; }
     if (tot >= (1ull << 32) - 64) return 0;
     WS(ent, u64, WS_RA_ENT, tot + 64); WS(rm, uint8_t, WS_RA_RM, tot + 64);
@@ -1321,6 +1324,7 @@ int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved
     const u64 heavyCap = 1 << 16; WS(heavy, u32, WS_RA_HEAVY, heavyCap);
     WS(ent32, u32, WS_RA_ENT32, tot + 64); WS(split, u32, WS_RA_SPLIT, N + 2);
     hipLaunchKernelGGL(k_ra_pack32, dim3((unsigned)std::min<u64>((N + 4) / 4, 256ull * 64)), dim3(256), 0, d->stream, ent, offs, deg, (u64)N, ent32, split);
+    lap("  final lists filled + 32-bit image");
     HIPCHK(hipEventRecord(d->ev[5], d->stream));                          // (marks_ms: the sharded part of the phase -- marks, removals, re-emission)
     if (nun) {
     hipLaunchKernelGGL((k_ra_mark<128, 8, 0, false>), dim3(gb), dim3(256), 0, d->stream, ids, (u64)nun, offs, deg, ent, ent32, split, rm, svn, d->d_counters + 8, heavy, heavyCap);     // lists of <= 128 entries
