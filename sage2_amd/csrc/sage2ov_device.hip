@@ -73,6 +73,7 @@ struct Device {
     // hits written out by the initial pass (k_probe_fast<..., TAIL = 2> on noisy data, one context probing everything): the reduce phase filters them
     struct PreHits { bool valid = false; Hit* hits = nullptr; u64 cap = 0, used = 0; u64* base = nullptr; } pre;
     void* s4keep = nullptr;      // step 4: the simplified graph stays in HBM until the next call (S4Keep)
+    void* rrStaging = nullptr;   // ranked reduce: the pinned 2 MB-page host buffers the potential lists are downloaded into, kept from step to step (RrStaging)
     // workspace arena: buffers of the timed path are allocated once and only ever grow (no hipMalloc/hipFree per step)
     struct Buf { void* p = nullptr; size_t cap = 0; };
     Buf ws[WS_COUNT];
@@ -145,7 +146,9 @@ Device* dev_create(int ordinal, std::string& err) {
     hipMemset(d->d_counters, 0, 24 * sizeof(u64));
     return d;
 }
+static void rr_staging_release(Device* d);
 static void free_reads(Device* d) {
+    rr_staging_release(d);                     // (pinned host buffers sized by the previous read set)
     hipFree(d->reads); hipFree(d->right); hipFree(d->left); hipFree(d->conn); hipFree(d->cflag);
     hipFree(d->status); hipFree(d->cand);     // slots / csr / final_edges live in the workspace arena
     for (auto& b : d->ws) { if (b.p) hipFree(b.p); b.p = nullptr; b.cap = 0; }
@@ -156,7 +159,7 @@ void dev_destroy(Device* d) {
     if (!d) return;
     hipSetDevice(d->ordinal);
     hipStreamSynchronize(d->stream);
-    dev_simplify_release(d);
+    dev_simplify_release(d); rr_staging_release(d);
     free_reads(d); hipFree(d->d_counters);
     for (auto& ev : d->ev) if (ev) hipEventDestroy(ev);
     hipStreamDestroy(d->stream);
@@ -936,6 +939,19 @@ struct HugeBuf {
     }
     ~HugeBuf() { if (p) { if (registered) hipHostUnregister(p); munmap(p, bytes); } }
 };
+struct RrStaging {                                       // slice s of a call reuses buffer s of the previous call when it is large enough
+    std::vector<std::unique_ptr<HugeBuf>> bufs; size_t next = 0;
+    u32* get(size_t n) {
+        const size_t want = (std::max<size_t>(n, 16) + 16) * sizeof(u32);
+        if (next < bufs.size() && bufs[next]->p && bufs[next]->bytes >= want) return (u32*)bufs[next++]->p;
+        std::unique_ptr<HugeBuf> b(new HugeBuf()); u32* p = (u32*)b->get(want + want / 8); if (!p) return nullptr;
+        memset(p, 0, b->bytes);                                  // (touch: the pages exist before they are pinned)
+        if (hipHostRegister(p, b->bytes, hipHostRegisterDefault) == hipSuccess) b->registered = true; else (void)hipGetLastError();
+        if (next < bufs.size()) bufs[next] = std::move(b); else bufs.push_back(std::move(b));
+        return (u32*)bufs[next++]->p;
+    }
+};
+static void rr_staging_release(Device* d) { if (d->rrStaging) { delete (RrStaging*)d->rrStaging; d->rrStaging = nullptr; } }
 constexpr u32 XO_MARK = 0x80000000u, XO_RK = 0x7FFFFFFFu, XO_IDM = 0x3FFFFFFFu;
 #if defined(__x86_64__)
 static inline void xo_relax() { __builtin_ia32_pause(); }
@@ -1241,11 +1257,10 @@ int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved
         for (u64 w = 0; w < nun; w++) hasCand[w] = hDeg[hIds[w]] != 0;
         if (timing) { u64 c512 = 0, c1k = 0, c4k = 0; u32 mx = 0; for (u32 v : hDegp) { c512 += v > 512; c1k += v > 1024; c4k += v > 4096; mx = std::max(mx, v); }
             fprintf(stderr, "[reduce/device] potential lists: %llu reads, > 512: %llu, > 1024: %llu, > 4096: %llu, longest %u\n", (unsigned long long)nun, (unsigned long long)c512, (unsigned long long)c1k, (unsigned long long)c4k, mx); }
-        struct Staging { std::vector<std::unique_ptr<HugeBuf>> bufs;
-                         u32* get(size_t n) { bufs.emplace_back(new HugeBuf()); HugeBuf& b = *bufs.back(); u32* p = (u32*)b.get((std::max<size_t>(n, 16) + 16) * sizeof(u32)); if (!p) return nullptr;
-                                              memset(p, 0, b.bytes);                                  // (touch: the pages exist before they are pinned)
-                                              if (hipHostRegister(p, b.bytes, hipHostRegisterDefault) == hipSuccess) b.registered = true; else (void)hipGetLastError();
-                                              return p; } } staging;   // gigabytes at 10 M reads: 2 MB pages for the host's walk, registered so that the download is a DMA
+        // gigabytes at 10 M reads: 2 MB pages for the host's walk, registered so that the download is a DMA; kept in the context from step to step (allocating, touching
+        // and registering 1.7 GB took 100 ms of every call)
+        if (!d->rrStaging) d->rrStaging = new RrStaging();
+        RrStaging& staging = *(RrStaging*)d->rrStaging; staging.next = 0;
         std::vector<std::vector<u32>> heavyLists;                                 // lists beyond the device sort (reads that thousands of others see): sorted and merged on the host
         u64 sliceEntries = 1ull << 30; if (const char* ev = getenv("SAGE2OV_TEST_RANK_SLICE")) sliceEntries = std::max<u64>(1024, strtoull(ev, nullptr, 10));
         WS(lenp, u32, WS_RR_LEN, nun + 2);
