@@ -1306,10 +1306,18 @@ int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved
         }
         { size_t hx = 0; for (u64 w = 0; w < nun; w++) if (hDegp[w] > (u32)RR_CAP) listPtr[w] = heavyLists[hx++].data(); }      // (after the last push_back: the vectors no longer move)
         lap("potential lists (build + sort + download)");
-        std::vector<u32> rankByPos, posOf(nun), startOrder;
-        for (u64 w = 0; w < nun; w++) posOf[w] = hLoc[hIds[w]];
-        { std::vector<uint8_t> isUn(N + 2, 0); for (u64 w = 0; w < nun; w++) isUn[hIds[w]] = 1; startOrder.reserve(nun); for (u64 id = 1; id <= N; id++) if (isUn[id]) startOrder.push_back(hLoc[id]); }
-        lap("walk set-up (host)");
+        std::vector<u32> rankByPos, posOf(nun), startOrder(nun);
+        {   // positions of the unresolved reads in list order and in ascending id order (the walk's starts): two gathers and a compaction, on the device
+            WS(sflg, u32, WS_RR_IN, N + 2); WS(sfpos, u32, WS_RR_WIDX, N + 2); WS(sout, u32, WS_RR_CUR, N + 2); WS(pout, u32, WS_RR_DEGP, nun + 2);
+            hipLaunchKernelGGL(k_ids_to_pos, dim3(grid_for(nun, 256)), dim3(256), 0, d->stream, ids, (u64)nun, d->posOf, pout);
+            hipLaunchKernelGGL(k_rr_start_flag, dim3(grid_for(N, 256)), dim3(256), 0, d->stream, (u64)N, d->status, sflg);
+            u64 cnt3 = 0; { int rc = scan_u32(d, sflg, N, sfpos, &cnt3, err); if (rc) return rc; }
+            if (cnt3 != nun) { err = "unresolved read count changed"; return SAGE2OV_ERR_INTERNAL; }
+            hipLaunchKernelGGL(k_rr_start_pick, dim3(grid_for(N, 256)), dim3(256), 0, d->stream, (u64)N, sflg, sfpos, d->posOf, sout);
+            HIPCHK(hipMemcpyAsync(posOf.data(), pout, nun * sizeof(u32), hipMemcpyDeviceToHost, d->stream));
+            HIPCHK(hipMemcpyAsync(startOrder.data(), sout, nun * sizeof(u32), hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
+        }
+        lap("walk set-up (device + download)");
         explore_order(posOf, listPtr, hLen, hasCand, N, startOrder, rankByPos);
         if (rankByPos.size() != N + 2) { err = "exploration walk: table allocation failed"; return SAGE2OV_ERR_NOMEM; }
         lap("exploration order (host)");
