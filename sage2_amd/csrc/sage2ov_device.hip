@@ -410,7 +410,10 @@ int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t
     if (const char* ev = getenv("SAGE2OV_MINIMIZER_INDEX")) wantMI = atoi(ev) != 0;
     if (getenv("SAGE2OV_NO_MINIMIZER_INDEX") || (d->h - std::min(d->h, 16) + 1) < 8) wantMI = false;
     u64 TL = 0; int tlBits = 0; u64 gW = 0;
-    if (wantMI) { TL = IX_GW; tlBits = IX_GWLOG; while (TL < d->T / 4) { TL <<= 1; tlBits++; } gW = TL / IX_GW; }   // >= 2N group words
+    // >= 3N group words (round 3; 2N before): a group window takes 256 x MIW_R = 2048 group tuples in registers and ~3N distinct keys spread over TL / 2048 windows, so with
+    // TL in [2N, 3N) most windows overflowed into the global scratch, the scratch ran out, and the groups were built and then given up ("crowded") for every read set
+    // between 24 M and 33 M unique reads -- 4 ms of build for nothing, found by timing sizes between configs[1] and configs[2] (tests/diag/groups_by_size.py)
+    if (wantMI) { TL = IX_GW; tlBits = IX_GWLOG; while (TL < d->T / 8 * 3) { TL <<= 1; tlBits++; } gW = TL / IX_GW; }
     const u64 nAlloc = std::max<u64>(4, (u64)n + 4);
     const u32 ntiles = (u32)((n + PT_TILE - 1) / PT_TILE);
     PtBufs B; B.W = wantMI ? 4 : 3;                                          // {K, M, entry, tag} with the groups, {K, entry, tag} without
@@ -494,6 +497,8 @@ int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t
                     fprintf(stderr, "[verify-mi] %llu of %llu entries do not find their bucket in their key's group\n", (unsigned long long)hv2[0], (unsigned long long)hv2[1]);
                 }
                 if (mc[2] == 0 && mc[1] * 10 <= TL * 7) { d->mi1 = mi1; d->krec = krec; d->TL = TL; }   // else: too crowded, the fast kernel uses the uniform table
+                if (timing) fprintf(stderr, "[index] minimiser groups: %llu groups, %llu records, %llu group words (load %.2f), crowded windows %llu -> %s\n", (unsigned long long)mc[1], (unsigned long long)mc[0],
+                                    (unsigned long long)TL, (double)mc[1] / (double)TL, (unsigned long long)mc[2], d->mi1 ? "used" : "NOT used");
             }
             break;
         }
