@@ -585,6 +585,18 @@ static void launch_fast(Device* d, ProbeArgs& A, unsigned blocks) {
     }
     hipLaunchKernelGGL((k_probe_fast<S, NW, WPL, WPB, HITS, TAIL, false>), dim3(blocks), dim3(64 * WPB), 0, d->stream, A);
 }
+// The sequential-groups form of the clean-data kernel (k_probe_fast<..., UNI, QN, SEQ>): read sets of one length in the 4- and 8-word layouts only; qn = 2 (128 candidates,
+// as the standard form) or 4 (256: the reads of high-coverage data the standard form lists).  false: no such instantiation for these reads.
+static bool launch_fast_seq_any(Device* d, ProbeArgs& A, unsigned blocks, int qn) {
+    constexpr int FW = SAGE2OV_FAST_WPB;
+    const int nwinMax = d->maxL - d->h + 1;
+    if (!d->uniL || nwinMax > 128) return false;
+    if (d->S == 4) { if (qn == 4) hipLaunchKernelGGL((k_probe_fast<4, 8, 2, FW, 0, 0, true, 4, true>), dim3(blocks), dim3(64 * FW), 0, d->stream, A);
+                     else hipLaunchKernelGGL((k_probe_fast<4, 8, 2, FW, 0, 0, true, 2, true>), dim3(blocks), dim3(64 * FW), 0, d->stream, A); return true; }
+    if (d->S == 8 && d->maxL <= 160) { if (qn == 4) hipLaunchKernelGGL((k_probe_fast<8, 10, 2, FW, 0, 0, true, 4, true>), dim3(blocks), dim3(64 * FW), 0, d->stream, A);
+                                       else hipLaunchKernelGGL((k_probe_fast<8, 10, 2, FW, 0, 0, true, 2, true>), dim3(blocks), dim3(64 * FW), 0, d->stream, A); return true; }
+    return false;
+}
 // picks the instantiation for the resident reads; false: the 32-word layout (505 .. 1018 bases) has no fast kernel
 template <int HITS, int TAIL>
 static bool launch_fast_any(Device* d, ProbeArgs& A, unsigned blocks) {
@@ -643,7 +655,7 @@ int dev_probe(Device* d, uint64_t lo, uint64_t hi, std::string& err) {
     HIPCHK(hipEventRecord(d->ev[0], d->stream));
     HIPCHK(hipMemsetAsync(d->right, 0, (N + 1) * sizeof(u64), d->stream)); HIPCHK(hipMemsetAsync(d->left, 0, (N + 1) * sizeof(u64), d->stream));
     HIPCHK(hipMemsetAsync(d->conn, 0, (N + 1) * sizeof(u32), d->stream)); HIPCHK(hipMemsetAsync(d->cflag, 0, (N + 1) * sizeof(u32), d->stream));
-    HIPCHK(hipMemsetAsync(d->d_counters + 6, 0, sizeof(u64), d->stream));
+    HIPCHK(hipMemsetAsync(d->d_counters + 6, 0, 2 * sizeof(u64), d->stream));          // [6] reads handed on, [7] of them: more candidates than the form has slots
     ProbeArgs A = base_args(d); A.lo = lo; A.hi = hi;
     const u64 nreads = hi > lo ? hi - lo : 0;
     d->pre.valid = false;
@@ -667,15 +679,17 @@ int dev_probe(Device* d, uint64_t lo, uint64_t hi, std::string& err) {
         u64 nsample = (nreads >= 4 * sampleMin && !evt) ? std::max<u64>(nreads / 128, sampleMin) : 0;   // (on noisy data the sample is work done twice)
         nsample = (nsample + FAST_CHUNK - 1) / FAST_CHUNK * FAST_CHUNK;
         int tailKernel = evt ? atoi(evt) : 1; bool anyListed = evt && tailKernel == 0;       // 0 / 1 / 2: see k_probe_fast
-        bool launched = true;
-        u64 nslow = 0; float kms = 0;
+        bool launched = true, mainWide = false;
+        u64 nslow = 0, ncap = 0; float kms = 0;
+        // the clean-data launches of one-length read sets run the sequential-groups form (eight waves per SIMD: -2.4 % at configs[2]); SAGE2OV_PROBE_SEQ=0: the standard form
+        const bool seqForm = !(getenv("SAGE2OV_PROBE_SEQ") && atoi(getenv("SAGE2OV_PROBE_SEQ")) == 0);
         auto timed = [&](auto&& launch) -> int {                              // one launch of the fast kernel between two events
             HIPCHK(hipEventRecord(d->ev[2], d->stream));
             launch();
             HIPCHK(hipGetLastError());
             HIPCHK(hipEventRecord(d->ev[3], d->stream));
-            HIPCHK(hipMemcpyAsync(&nslow, d->d_counters + 6, sizeof nslow, hipMemcpyDeviceToHost, d->stream));
-            HIPCHK(hipStreamSynchronize(d->stream));
+            u64 c2_[2] = {0, 0}; HIPCHK(hipMemcpyAsync(c2_, d->d_counters + 6, sizeof c2_, hipMemcpyDeviceToHost, d->stream));
+            HIPCHK(hipStreamSynchronize(d->stream)); nslow = c2_[0]; ncap = c2_[1];
             float ms = 0; hipEventElapsedTime(&ms, d->ev[2], d->ev[3]); kms += ms; d->tm.probe_fast_launches++;
             if (getenv("SAGE2OV_TIMING")) fprintf(stderr, "[probe] fast kernel launch %.3f ms, listed so far %llu\n", ms, (unsigned long long)nslow);
             return 0;
@@ -702,18 +716,22 @@ int dev_probe(Device* d, uint64_t lo, uint64_t hi, std::string& err) {
         };
         if (nsample && nsample < nreads) {
             ProbeArgs As = A; As.hi = lo + nsample;
-            int rc = timed([&] { launched = launch_fast_any<0, 0>(d, As, plan_fast_grid(As, nsample)); }); if (rc) return rc;
+            int rc = timed([&] { const unsigned nbs = plan_fast_grid(As, nsample); launched = (seqForm && launch_fast_seq_any(d, As, nbs, 2)) || launch_fast_any<0, 0>(d, As, nbs); }); if (rc) return rc;
             if (launched) {
                 anyListed = true;
-                tailKernel = nslow * 2 > nsample ? 2 : (nslow * 32 > nsample ? 1 : 0);   // listed: more than half -> state machine for every read; more than 3 % -> kernel that carries it
+                // listed for being inconsistent: more than half -> state machine for every read; more than 3 % -> kernel that carries it.  Listed for having more candidates
+                // than slots (high coverage), more than 3 %: the rest runs the WIDE form (256 slots) right away instead of listing a fifth of the reads again
+                const u64 nInc = nslow - std::min(nslow, ncap);
+                tailKernel = nInc * 2 > nsample ? 2 : (nInc * 32 > nsample ? 1 : 0);
+                mainWide = tailKernel == 0 && ncap * 32 > nsample && d->uniL != 0 && !getenv("SAGE2OV_NO_WIDE");
                 ProbeArgs Ar = A; Ar.lo = lo + nsample; const unsigned nb = plan_fast_grid(Ar, nreads - nsample, tailKernel == 2);
                 bool armed = false; { int rca = arm_prehits(Ar, nreads - nsample, nb, armed); if (rca) return rca; }
-                rc = timed([&] { if (tailKernel == 2) launch_fast_any<0, 2>(d, Ar, nb); else if (tailKernel == 1) launch_fast_any<0, 1>(d, Ar, nb); else launch_fast_any<0, 0>(d, Ar, nb); }); if (rc) return rc;
+                rc = timed([&] { if (tailKernel == 2) launch_fast_any<0, 2>(d, Ar, nb); else if (tailKernel == 1) launch_fast_any<0, 1>(d, Ar, nb); else if (!((mainWide && launch_fast_seq_any(d, Ar, nb, 4)) || (seqForm && launch_fast_seq_any(d, Ar, nb, 2)))) launch_fast_any<0, 0>(d, Ar, nb); }); if (rc) return rc;
                 if (armed) { int rca = close_prehits(); if (rca) return rca; }
             }
         } else {
             ProbeArgs Aw = A; const unsigned nb = plan_fast_grid(Aw, nreads, tailKernel == 2); bool armed = false; { int rca = arm_prehits(Aw, nreads, nb, armed); if (rca) return rca; }
-            int rc = timed([&] { launched = tailKernel == 2 ? launch_fast_any<0, 2>(d, Aw, nb) : (tailKernel == 1 ? launch_fast_any<0, 1>(d, Aw, nb) : launch_fast_any<0, 0>(d, Aw, nb)); }); if (rc) return rc;
+            int rc = timed([&] { launched = tailKernel == 2 ? launch_fast_any<0, 2>(d, Aw, nb) : (tailKernel == 1 ? launch_fast_any<0, 1>(d, Aw, nb) : ((seqForm && launch_fast_seq_any(d, Aw, nb, 2)) || launch_fast_any<0, 0>(d, Aw, nb))); }); if (rc) return rc;
             if (armed && launched) { int rca = close_prehits(); if (rca) return rca; }
         }
         if (!launched) {                                                       // 32-word layout: sequential kernel only
@@ -723,9 +741,22 @@ int dev_probe(Device* d, uint64_t lo, uint64_t hi, std::string& err) {
             float ms = 0; hipEventElapsedTime(&ms, d->ev[2], d->ev[3]); kms += ms; nslow = 0;
         }
         u32* list = slow;
+        // Reads the 128-slot forms listed, many of them (high coverage: more than 128 candidates; tests/diag/coverage_sweep.py): first the WIDE sequential-groups form
+        // (256 candidate slots, no state machine); what it lists in turn -- inconsistent reads, more than 256 candidates -- goes on as before.
+        const u64 wideMin = getenv("SAGE2OV_PROBE_WIDE_MIN") ? strtoull(getenv("SAGE2OV_PROBE_WIDE_MIN"), nullptr, 10) : 4096;
+        if (launched && anyListed && nslow >= wideMin && tailKernel != 2 && !mainWide && d->uniL && !getenv("SAGE2OV_NO_WIDE")) {
+            WS(slow2, u32, WS_SLOW2, nslow);
+            HIPCHK(hipMemsetAsync(d->d_counters + 6, 0, 2 * sizeof(u64), d->stream));
+            ProbeArgs B = base_args(d); B.ids = slow; B.n_ids = nslow; B.slow = slow2; B.slow_cap = nslow;
+            const u64 nl = nslow; const unsigned nbl = plan_fast_grid(B, nl); bool wide = false;
+            int rc = timed([&] { wide = launch_fast_seq_any(d, B, nbl, 4); }); if (rc) return rc;
+            if (wide) {                                                          // (the survivors' list becomes the list: copied back so that the steps below find it where they expect it)
+                if (nslow) HIPCHK(hipMemcpyAsync(slow, slow2, nslow * sizeof(u32), hipMemcpyDeviceToDevice, d->stream));
+            } else nslow = nl;
+        }
         if (launched && anyListed && nslow) {                                  // listed by the TAIL = 0 kernel: the state machine, in the TAIL = 1 kernel
             WS(slow2, u32, WS_SLOW2, nslow);
-            HIPCHK(hipMemsetAsync(d->d_counters + 6, 0, sizeof(u64), d->stream));
+            HIPCHK(hipMemsetAsync(d->d_counters + 6, 0, 2 * sizeof(u64), d->stream));
             ProbeArgs B = base_args(d); B.ids = slow; B.n_ids = nslow; B.slow = slow2; B.slow_cap = nslow;
 #ifdef SAGE2OV_STAMPS
             B.stamps = A.stamps;

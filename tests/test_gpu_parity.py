@@ -873,6 +873,34 @@ def test_tapered_grid_of_the_fast_kernel_is_exact(pd, k, phase_blocks, monkeypat
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["wide_pass", "sequential_form", "both", "standard_form", "sampled_route"])
+@pytest.mark.parametrize("pd,k", [
+    (dict(seed=91, genome_len=16000, n_reads=16000, read_len=150, err_ppm=0), 40),       # 150x: most reads have 129 .. 256 candidates
+    (dict(seed=92, genome_len=9000, n_reads=14000, read_len=100, err_ppm=0), 31),        # 155x of 100-base reads (4-word layout)
+    (dict(seed=93, genome_len=20000, n_reads=16000, read_len=150, err_ppm=300), 40),     # with a few read errors: inconsistent reads go on to the state machine
+    (dict(seed=94, genome_len=8000, n_reads=20000, read_len=150, err_ppm=0), 40),        # 375x: beyond 256 candidates, the sequential kernel as before
+])
+def test_sequential_groups_form_and_wide_pass_are_exact(pd, k, mode, monkeypatch):
+    """The clean-data probe kernel has a form that gathers and compares its 64-slot candidate groups one after the other (k_probe_fast<..., UNI, QN, SEQ>): with two
+    groups it replaces the standard form (SAGE2OV_PROBE_SEQ), with four it takes the reads of high-coverage data that the 128-slot forms list (more than 128 candidates)
+    before anything goes to the state machine or the sequential kernel.  Same records, counters and edges as the oracle either way."""
+    if mode in ("wide_pass", "both"):
+        monkeypatch.setenv("SAGE2OV_PROBE_WIDE_MIN", "1")
+    elif mode != "sampled_route":
+        monkeypatch.setenv("SAGE2OV_NO_WIDE", "1")
+    monkeypatch.setenv("SAGE2OV_PROBE_SEQ", "1" if mode in ("sequential_form", "both", "sampled_route") else "0")   # (0: the standard form, both groups in flight together)
+    if mode == "sampled_route":                                                     # the host's own route: a sample counts the reads with too many candidates and picks the wide form for the rest
+        monkeypatch.setenv("SAGE2OV_PROBE_SAMPLE_MIN", "1024"); monkeypatch.setenv("SAGE2OV_PROBE_WIDE_MIN", "1")
+    else:
+        monkeypatch.setenv("SAGE2OV_PROBE_TAIL", "0")                               # (the form that lists what it cannot settle: the wide pass works on that list)
+    bases, off = fx.make_reads(pd)
+    m = dict(k=k)
+    g, o = run_gpu(m, bases, off), run_oracle(m, bases, off)
+    assert_equals_oracle(g, o)
+    g.close(); o.close()
+
+
+@pytest.mark.gpu
 def test_reads_beyond_the_longest_layout_are_refused():
     """1018 bases is the limit of the 32-word layout; a longer read is reported by the organiser (ASCII and device-pack path alike), not truncated."""
     pd = dict(seed=5, genome_len=20000, n_reads=300, read_len=1019, read_len_min=900)
