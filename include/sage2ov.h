@@ -48,6 +48,9 @@ typedef struct sage2ov_config {
 
 #define SAGE2OV_FLAG_HOST_REDUCE 1u  /* force the exact serial BFS replay (economyGraph.cpp:513-564) on the host
                                         even when the order-independent device form would be exact */
+#define SAGE2OV_FLAG_ASYNC_DEVICE 2u /* open the device on a helper thread: sage2ov_ctx_create returns at once and the caller parses its
+                                        input files meanwhile (the HIP runtime takes ~0.2 s to start).  The first call that needs the
+                                        device waits for it; a device that cannot be opened is reported there (SAGE2OV_ERR_DEVICE) */
 
 /* ---- lifetime: replaces new/delete of the four classes (main.cpp:44,76,108,116) ---- */
 int  sage2ov_ctx_create(const sage2ov_config* cfg, sage2ov_ctx** out);

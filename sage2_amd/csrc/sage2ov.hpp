@@ -13,8 +13,8 @@ struct Error : std::runtime_error { int code; Error(int c, const std::string& m)
 
 class Context {
 public:
-    explicit Context(uint16_t minOvlp, int device = SAGE2OV_DEVICE_CURRENT, unsigned hostThreads = 0, unsigned rank = 0, unsigned world = 1) {
-        sage2ov_config cfg{}; cfg.min_overlap = minOvlp; cfg.device = device; cfg.rank = rank; cfg.world = world; cfg.host_threads = hostThreads;
+    explicit Context(uint16_t minOvlp, int device = SAGE2OV_DEVICE_CURRENT, unsigned hostThreads = 0, unsigned rank = 0, unsigned world = 1, unsigned flags = 0) {
+        sage2ov_config cfg{}; cfg.min_overlap = minOvlp; cfg.device = device; cfg.rank = rank; cfg.world = world; cfg.host_threads = hostThreads; cfg.flags = flags;
         int rc = sage2ov_ctx_create(&cfg, &c_); if (rc) throw Error(rc, sage2ov_last_error(nullptr));
     }
     ~Context() { sage2ov_ctx_destroy(c_); }

@@ -198,11 +198,13 @@ static int partition_by_window(Device* d, PtBufs& B, int keyw, u32 n, int shiftW
 // Step 1 on the device: see k_org_canon.  On return the read store is resident exactly as after dev_upload_reads, and the
 // host receives the image (for the .reads writer, lengths) and the frequencies.
 int dev_organize_reads(Device* d, const uint64_t* pool, uint64_t pool_words, const uint64_t* off, const uint16_t* len, uint64_t n, int S, int minL, int maxL, int k,
-                       uint64_t* N_out, std::vector<uint64_t>& words_out, std::vector<uint16_t>& freq_out, std::string& err, OrgAscii* ascii) {
+                       uint64_t* N_out, RawU64& words_out, RawU16& freq_out, std::string& err, OrgAscii* ascii) {
     HIPCHK(hipSetDevice(d->ordinal));
     struct EvPair { hipEvent_t a = nullptr, b = nullptr; ~EvPair() { if (a) hipEventDestroy(a); if (b) hipEventDestroy(b); } } evp;   // (destroyed on every return path)
     HIPCHK(hipEventCreate(&evp.a)); HIPCHK(hipEventCreate(&evp.b));
     const hipEvent_t e0 = evp.a, e1 = evp.b;
+    const bool timing = getenv("SAGE2OV_TIMING") != nullptr; auto tp = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) { if (!timing) return; hipStreamSynchronize(d->stream); auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[step 1/device] %-30s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(t - tp).count()); tp = t; };
     HIPCHK(hipEventRecord(e0, d->stream));
     // ASCII input (sage2ov_reads_add_ascii): filter, 2-bit pack and canonical orientation on the device (utils.cpp:144-166, :96-119, readLoader.cpp:195)
     unsigned char* dbases = nullptr; u64* doffA = nullptr; u32* gflag = nullptr; u32* gpos = nullptr;
@@ -235,6 +237,7 @@ int dev_organize_reads(Device* d, const uint64_t* pool, uint64_t pool_words, con
             HIPCHK(hipMemsetAsync(dpool + pool_words, 0, 17 * sizeof(u64), d->stream));
             HIPCHK(hipMemcpyAsync(doff, off, n * sizeof(u64), hipMemcpyHostToDevice, d->stream));
             HIPCHK(hipMemcpyAsync(dlen, len, n * sizeof(uint16_t), hipMemcpyHostToDevice, d->stream));
+            lap("work space + upload");
             hipLaunchKernelGGL(k_org_canon, dim3(grid_for(n, 256)), dim3(256), 0, d->stream, dpool, doff, dlen, (u64)n, S, img, k0, v0);
         }
         const u32 nb = (u32)((n + RS_TILE - 1) / RS_TILE);
@@ -269,6 +272,7 @@ int dev_organize_reads(Device* d, const uint64_t* pool, uint64_t pool_words, con
         if (N >= (1ull << 30)) { err = "more than 2^30-1 unique reads per context is not supported yet"; return SAGE2OV_ERR_LIMIT; }
         WS(headPos, u32, WS_ORG_HEAD, N + 2);
         hipLaunchKernelGGL(k_org_headpos, dim3(grid_for(n, 256)), dim3(256), 0, d->stream, flag, uid, (u64)n, headPos, (u64)N);
+        lap("canonical, sort, heads");
         HIPCHK(hipMalloc(&reads, (N + 1) * S * sizeof(u64))); HIPCHK(hipMalloc(&dfreq, (N + 1) * sizeof(unsigned short)));
         HIPCHK(hipMemsetAsync(reads, 0, S * sizeof(u64), d->stream)); HIPCHK(hipMemsetAsync(dfreq, 0, sizeof(unsigned short), d->stream));
         hipLaunchKernelGGL(k_org_gather, dim3(grid_for_capped(N * S, 256)), dim3(256), 0, d->stream, va, headPos, (u64)N, img, S, reads, dfreq);
@@ -278,10 +282,14 @@ int dev_organize_reads(Device* d, const uint64_t* pool, uint64_t pool_words, con
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(e1, d->stream));
+    lap("read store allocation + gather");
     words_out.resize((N + 1) * S); freq_out.resize(N + 1);
+    touch_pages(words_out.data(), words_out.size() * sizeof(u64), 8);
+    lap("host vectors (resize, first touch)");
     HIPCHK(hipMemcpyAsync(words_out.data(), reads, (N + 1) * S * sizeof(u64), hipMemcpyDeviceToHost, d->stream));
     HIPCHK(hipMemcpyAsync(freq_out.data(), dfreq, (N + 1) * sizeof(unsigned short), hipMemcpyDeviceToHost, d->stream));
     HIPCHK(hipStreamSynchronize(d->stream));
+    lap("download of the store");
     float ms = 0; hipEventElapsedTime(&ms, e0, e1); d->tm.organize_ms += ms;
     hipFree(dfreq);
     // the organised store becomes the context's read store (same state as after dev_upload_reads)
@@ -292,6 +300,7 @@ int dev_organize_reads(Device* d, const uint64_t* pool, uint64_t pool_words, con
     for (int id : {WS_ORG_POOL, WS_ORG_OFF, WS_ORG_LEN, WS_ORG_IMG, WS_ORG_K0, WS_ORG_K1, WS_ORG_V0, WS_ORG_V1, WS_ORG_HIST, WS_ORG_HSCAN, WS_ORG_FLAG, WS_ORG_UID, WS_ORG_HEAD, WS_ORG_GFLAG, WS_ORG_GPOS}) ws_free(d, id);
     decide_diet(d);
     if (!d->diet) { int rc = ensure_results(d, err); if (rc) return rc; }
+    lap("release + result buffers");
     *N_out = N;
     return 0;
 }

@@ -2,7 +2,11 @@
 // and the device side (sage2ov_device.hip, hipcc).  Plain C++ structs, no HIP types leak out.
 #pragma once
 #include <cstdint>
+#include <algorithm>
+#include <memory>
 #include <string>
+#include <thread>
+#include <utility>
 #include <vector>
 
 namespace s2 {
@@ -63,10 +67,24 @@ int dev_unresolved_hits(Device* d, std::vector<Hit>& hits, uint64_t* n_unresolve
 int dev_download_status(Device* d, std::vector<uint8_t>& status, std::string& err);
 int dev_unresolved_ids(Device* d, std::vector<uint32_t>& ids, std::string& err);          // ascending
 int dev_collect_reduce_edges(Device* d, const std::vector<uint32_t>& unresolved, std::vector<EdgeCand>& out, std::string& err);
+// host arrays of hundreds of MB that are overwritten right after they are sized: resize() must not write zeros through them on one thread
+template <class T> struct NoInitAlloc : std::allocator<T> {
+    template <class U> struct rebind { using other = NoInitAlloc<U>; };
+    template <class U, class... A> void construct(U* p, A&&... a) { if constexpr (sizeof...(A) == 0) ::new ((void*)p) U; else ::new ((void*)p) U(std::forward<A>(a)...); }
+};
+using RawU64 = std::vector<uint64_t, NoInitAlloc<uint64_t>>;
+using RawU16 = std::vector<uint16_t, NoInitAlloc<uint16_t>>;
+// first touch of a freshly sized array by `nt` threads (a copy into it on one thread would take its page faults one by one); the content is about to be overwritten
+inline void touch_pages(void* p, size_t bytes, int nt) {
+    if (bytes < (64u << 20) || nt < 2) return;
+    std::vector<std::thread> th; const size_t per = (bytes / nt + 4095) & ~(size_t)4095;
+    for (int t = 0; t < nt; t++) th.emplace_back([=] { char* b = (char*)p; const size_t a = per * t, e = std::min(bytes, a + per); for (size_t x = a; x < e; x += 4096) b[x] = 0; });
+    for (auto& x : th) x.join();
+}
 // ASCII input of step 1 (sage2ov_reads_add_ascii): raw bases + offsets in, filter / pack / canonical orientation on the device; the counters come back
 struct OrgAscii { const char* bases; uint64_t nbytes; const uint64_t* off; uint64_t n_in; uint64_t good = 0, total_bp = 0, small = 0; int maxL = 0, minL = 0, S = 0; };
 int dev_organize_reads(Device* d, const uint64_t* pool, uint64_t pool_words, const uint64_t* off, const uint16_t* len, uint64_t n, int S, int minL, int maxL, int k,
-                       uint64_t* N_out, std::vector<uint64_t>& words_out, std::vector<uint16_t>& freq_out, std::string& err, OrgAscii* ascii = nullptr);
+                       uint64_t* N_out, RawU64& words_out, RawU16& freq_out, std::string& err, OrgAscii* ascii = nullptr);
 int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved, uint64_t* n_hits, uint64_t* inserted, uint64_t* removed, int* done, std::string& err,
                       uint32_t shareRank = 0, uint32_t shareWorld = 1);
 int dev_export_cand_range(Device* d, void* dev_dst, uint64_t first, uint64_t n, std::string& err);

@@ -9,7 +9,7 @@ tmp = tempfile.mkdtemp(); fa = os.path.join(tmp, "x.fa"); out = os.path.join(tmp
 t0 = time.time(); s2.synth_write_fasta(p, fa); t1 = time.time()
 print("fasta written: %.1f s, %.0f MB" % (t1 - t0, os.path.getsize(fa) / 1e6))
 t0 = time.time()
-subprocess.run([os.path.join(R, "sage2_amd", "sage2ov"), "-f", fa, "-k", "40", "-o", out, "-p", "t", "-M", max_step], check=True)
+subprocess.run([os.path.join(R, "sage2_amd", "sage2ov"), "-f", fa, "-k", "40", "-o", out, "-p", "t", "-M", max_step], check=True, env=dict(os.environ, SAGE2OV_TIMING="1"))
 print("CLI total: %.2f s" % (time.time() - t0))
 log = open(os.path.join(out, "t.log")).read()
 print("\n".join(l for l in log.splitlines() if "ime" in l or "sec" in l or "written" in l)[:1500])

@@ -158,7 +158,7 @@ def _export(path, k, sequential, monkeypatch):
     return out, (st.total_reads, st.good_reads, st.unique_reads, st.total_bp)
 
 
-@pytest.mark.parametrize("form", ["fasta", "fasta_multiline_crlf", "fastq", "fastq_at_quality", "fastq_multiline", "fastq_bad_record"])
+@pytest.mark.parametrize("form", ["fasta", "fasta_crlf", "fasta_inner_space", "fasta_mixed_shapes", "fasta_multiline_crlf", "fastq", "fastq_at_quality", "fastq_multiline", "fastq_bad_record"])
 def test_parallel_file_reader_equals_sequential_reader(form, tmp_path, monkeypatch):
     """files above 1 MB are mapped, cut at record starts and parsed by all threads (sage2ov_host.cpp::add_plain_file_parallel); multi-line
     FASTQ and anything that does not parse strictly fall back to the sequential reader -- same read set, same counters, either way"""
@@ -170,6 +170,17 @@ def test_parallel_file_reader_equals_sequential_reader(form, tmp_path, monkeypat
         for i, s in enumerate(seqs):
             if form == "fasta":
                 f.write(f">r{i}\n{s}\n")
+            elif form == "fasta_crlf":
+                f.write(f">r{i}\r\n{s}\r\n")
+            elif form == "fasta_inner_space":         # white space inside a sequence line is dropped by the reader (every 97th record; a tab in every 389th)
+                f.write(f">r{i}\n{s[:11] + ' ' + s[11:] if i % 97 == 5 else (s[:60] + chr(9) + s[60:] + ' ' if i % 389 == 7 else s)}\n")
+            elif form == "fasta_mixed_shapes":        # one-line records with a two-line record, an empty record and a '>' inside a header now and then
+                if i % 1013 == 3:
+                    f.write(f">r{i} >x\n{s[:40]}\n{s[40:]}\n")
+                elif i % 1999 == 4:
+                    f.write(f">r{i}\n\n")
+                else:
+                    f.write(f">r{i}\n{s}\n")
             elif form == "fasta_multiline_crlf":
                 f.write(f">r{i} x\r\n{s[:37]}\r\n{s[37:]}\r\n")
             elif form == "fastq":

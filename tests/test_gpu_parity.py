@@ -301,6 +301,25 @@ def test_cli_steps_1_to_3_write_reference_files(tmp_path):
     assert os.path.getsize(os.path.join(out, "h.hashTable")) == m["hashtable_size"] and fx.md5_file(os.path.join(out, "h.hashTable")) == m["hashtable_md5"]
 
 
+def test_device_opened_in_the_background_gives_the_same_graph_and_reports_a_bad_device_late(tmp_path):
+    """SAGE2OV_FLAG_ASYNC_DEVICE (what the CLI uses: the HIP runtime starts while step 1 parses its files): create returns at once, the first call
+    that needs the device joins the helper thread -- same files as the golden ones; a device that cannot be opened is reported by that call, as
+    SAGE2OV_ERR_DEVICE, not swallowed and not a crash"""
+    m = fx.golden("g6_k70_150")
+    fa = str(tmp_path / "x.fa"); s2.synth_write_fasta(fx.synth_params(m["synth"]), fa)
+    c = s2.Context(m["k"], device=0, flags=2)
+    c.reads_add_file(fa); c.reads_organize(); c.run_steps23()
+    gp = str(tmp_path / "t.graph3"); c.graph_save(gp); rp = str(tmp_path / "t.reads"); c.reads_save(rp)
+    assert open(gp, "rb").read() == fx.golden_graph3("g6_k70_150") and fx.md5_file(rp) == m["reads_md5"]
+    c.close()
+    bad = s2.Context(m["k"], device=97, flags=2)           # (without the flag, create itself fails: test_abi)
+    bad.reads_add_file(fa)
+    with pytest.raises(s2.Sage2ovError) as ei:
+        bad.reads_organize()
+    assert ei.value.code == -3 and str(ei.value)
+    bad.close()
+
+
 @pytest.mark.parametrize("name", ["g1_clean100_k21", "g4_highcopy_k21", "g5_mixedlen_k21"])
 def test_hashtable_file_from_a_device_organised_context(name, tmp_path):
     """SURVEY 8f-4 on the GPU path: reads organised ON THE DEVICE (ids, order, dedupe from k_org_*), index built, and P.hashTable written from that
