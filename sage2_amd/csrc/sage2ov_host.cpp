@@ -524,7 +524,8 @@ static int write_formatted(sage2ov_ctx* c, FILE* f, uint64_t n, size_t bytes_per
     const int nt = io_threads(c); HostLap lap("writer");
     if (fflush(f) != 0) return c->fail(SAGE2OV_ERR_IO, "write failed");
     const off_t pos0 = ftello(f); const int fd = fileno(f);
-    const uint64_t per = std::max<uint64_t>(256, (4u << 20) / std::max<size_t>(bytes_per_item, 1)), nchunks = (n + per - 1) / per;
+    // (items of very uneven size -- the edges of P.graph4 carry read lists -- still give every thread several chunks)
+    const uint64_t per = std::max<uint64_t>(64, std::min<uint64_t>((4u << 20) / std::max<size_t>(bytes_per_item, 1), (n + (uint64_t)nt * 8 - 1) / ((uint64_t)nt * 8))), nchunks = (n + per - 1) / per;
     std::unique_ptr<std::atomic<int64_t>[]> at(new std::atomic<int64_t>[nchunks + 1]);
     for (uint64_t j = 0; j <= nchunks; j++) at[j].store(-1, std::memory_order_relaxed);
     at[0].store((int64_t)pos0);
@@ -1179,7 +1180,9 @@ int sage2ov_simplify_stats_get(const sage2ov_ctx* c, sage2ov_simplify_stats* o) 
 int sage2ov_graph4_save(sage2ov_ctx* c, const char* path) {                           // overlapGraph.cpp:338-369, :12-20
     if (!c || !path) return SAGE2OV_ERR_ARG;
     if (!c->g4Valid) return c->fail(SAGE2OV_ERR_ARG, "sage2ov_graph4_save: call sage2ov_graph_simplify first");
+    HostLap lap("graph4");
     { int rc = dev_simplify_download(c->device(), c->g4, c->err); if (rc) return rc; }
+    lap("download of the simplified graph");
     const SimplifiedGraph& g = c->g4; const uint64_t N = g.N, nh = g.n_half_edges;
     // a node's list, oldest first = its alive half-edges by ascending index (the writer walks each list from its tail, :356-358)
     std::vector<uint32_t> offs(N + 2, 0), order;
@@ -1200,6 +1203,7 @@ int sage2ov_graph4_save(sage2ov_ctx* c, const char* path) {                     
             for (uint32_t x = 0; x < g.cnt[h]; x += 4096) items.push_back(Item{h, x, std::min<uint32_t>(4096, g.cnt[h] - x)});
             items.push_back(Item{h, ~0u, 1});
         }
+    lap("edge order + items");
     int rc = write_formatted(c, f, items.size(), 64, [&](uint64_t x, std::string& o) {
         const Item it = items[x]; const uint32_t h = it.h; char buf[96]; char* p;
         if (it.first == ~0u) { o.push_back('\n'); return; }
