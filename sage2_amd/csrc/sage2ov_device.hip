@@ -73,18 +73,27 @@ struct Device {
     // hits written out by the initial pass (k_probe_fast<..., TAIL = 2> on noisy data, one context probing everything): the reduce phase filters them
     struct PreHits { bool valid = false; Hit* hits = nullptr; u64 cap = 0, used = 0; u64* base = nullptr; } pre;
     void* s4keep = nullptr;      // step 4: the simplified graph stays in HBM until the next call (S4Keep)
+    // step 4: blocks a call released, kept for the next call (it asks for the same ~50 sizes; fresh HBM costs ~50 ms per GB to map, 0.7 s per call at BASELINE
+    // configs[2]).  Emptied when the read set changes, when the workspace arena runs out of memory, and never filled in memory-diet mode.
+    std::vector<std::pair<void*, size_t>> s4cache;
     void* rrStaging = nullptr;   // ranked reduce: the pinned 2 MB-page host buffers the potential lists are downloaded into, kept from step to step (RrStaging)
     // workspace arena: buffers of the timed path are allocated once and only ever grow (no hipMalloc/hipFree per step)
     struct Buf { void* p = nullptr; size_t cap = 0; };
     Buf ws[WS_COUNT];
 };
+static void s4cache_release(Device* d) { for (auto& c : d->s4cache) hipFree(c.first); d->s4cache.clear(); }
 static void* ws_get(Device* d, int id, size_t bytes) {
     Device::Buf& b = d->ws[id];
     if (b.cap < bytes || !b.p) {
         if (b.p) hipFree(b.p);
         b.p = nullptr; b.cap = 0;
         size_t want = d->diet ? bytes + 256 : bytes + bytes / 16 + 256;        // (grow-only arena: 6 % of slack saves re-allocations; none when memory is what is short)
-        if (hipMalloc(&b.p, want) != hipSuccess) { b.p = nullptr; return nullptr; }
+        if (hipMalloc(&b.p, want) != hipSuccess) {
+            (void)hipGetLastError(); b.p = nullptr;
+            if (d->s4cache.empty()) return nullptr;
+            s4cache_release(d);                                                       // (step 4's spare blocks go first)
+            if (hipMalloc(&b.p, want) != hipSuccess) { b.p = nullptr; return nullptr; }
+        }
         b.cap = want;
     }
     return b.p;
@@ -152,6 +161,7 @@ static void free_reads(Device* d) {
     hipFree(d->reads); hipFree(d->right); hipFree(d->left); hipFree(d->conn); hipFree(d->cflag);
     hipFree(d->status); hipFree(d->cand);     // slots / csr / final_edges live in the workspace arena
     for (auto& b : d->ws) { if (b.p) hipFree(b.p); b.p = nullptr; b.cap = 0; }
+    s4cache_release(d);
     d->readsLoc = nullptr; d->idOf = d->posOf = nullptr; d->statusP = nullptr; d->metaP = nullptr; d->mi1 = d->krec = nullptr; d->cand_cap = 0; d->n_cand = 0;
     d->reads = d->slots = nullptr; d->csr = nullptr; d->right = d->left = nullptr; d->conn = d->cflag = nullptr; d->status = nullptr; d->cand = nullptr; d->final_edges = nullptr;
 }
@@ -390,6 +400,7 @@ static void pt_first_digit(u64 nWin, int shiftW, int* shift0, u32* mask0, int* d
 int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t* csr_out, uint64_t* nlong_out, uint32_t* rebuilds, std::string& err) {
     HIPCHK(hipSetDevice(d->ordinal));
     const u64 N = d->N; if (!d->reads && !d->readsLoc) { err = "reads not resident"; return SAGE2OV_ERR_ARG; }
+    s4cache_release(d);                                                   // (a new step 2: step 4's spare blocks must not stand in the way of steps 2-3; empty unless step 4 ran since)
     HIPCHK(hipEventRecord(d->ev[0], d->stream));                          // (the locality store is part of the build and of index_ms)
     if (d->reads) { int rc = build_locality_store(d, err); if (rc) return rc; }
     // (diet mode, second and later builds: the id-ordered store was released after the first one; the locality-ordered store and its tables are what
@@ -1633,11 +1644,21 @@ int dev_convert(Device* d, uint64_t* n_final, std::string& err) {
 // step 4: simplification of the overlap graph in HBM (main.cpp:139-172).  Input: the final edges of step 3 (device resident, .graph3 order).
 // =============================================================================================
 namespace {
-struct S4Mem {                                   // freed on every exit path
-    std::vector<void*> ptrs;
-    template <class T> T* get(size_t n, std::string& err) { void* p = nullptr; if (hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) { err = "step 4: device allocation failed"; return nullptr; } ptrs.push_back(p); return (T*)p; }
-    void drop(void* p) { for (auto& q : ptrs) if (q == p) { hipFree(q); q = nullptr; } }
-    ~S4Mem() { for (void* p : ptrs) if (p) hipFree(p); }
+struct S4Mem {                                   // released on every exit path -- into the device's cache of step-4 blocks (Device::s4cache), or freed in diet mode
+    Device* d = nullptr;
+    std::vector<std::pair<void*, size_t>> ptrs;
+    void* take(size_t bytes) {
+        for (auto& c : d->s4cache) if (c.second == bytes) { void* p = c.first; c = d->s4cache.back(); d->s4cache.pop_back(); return p; }
+        void* p = nullptr;
+        if (hipMalloc(&p, bytes) == hipSuccess) return p;
+        (void)hipGetLastError();
+        s4cache_release(d);                                                           // (blocks of other sizes are in the way)
+        return hipMalloc(&p, bytes) == hipSuccess ? p : nullptr;
+    }
+    template <class T> T* get(size_t n, std::string& err) { const size_t bytes = std::max<size_t>(n, 1) * sizeof(T); void* p = take(bytes); if (!p) { (void)hipGetLastError(); err = "step 4: device allocation failed"; return nullptr; } ptrs.push_back({p, bytes}); return (T*)p; }
+    void give_back(void* p, size_t bytes) { if (d->diet) hipFree(p); else d->s4cache.push_back({p, bytes}); }
+    void drop(void* p) { for (auto& q : ptrs) if (q.first == p) { give_back(q.first, q.second); q.first = nullptr; } }
+    ~S4Mem() { for (auto& q : ptrs) if (q.first) give_back(q.first, q.second); }
 };
 }
 #define S4GET(var, type, n) type* var = mem.get<type>((n), err); if (!var) return SAGE2OV_ERR_NOMEM;
@@ -1651,7 +1672,7 @@ int dev_simplify(Device* d, SimplifiedGraph& out, std::string& err) {
     dev_simplify_release(d);
     lap("release of the previous result");
     std::unique_ptr<S4Keep> keep(new S4Keep());
-    S4Mem& mem = keep->mem; S4Graph& g = keep->g;
+    S4Mem& mem = keep->mem; S4Graph& g = keep->g; mem.d = d;
     const u64 N64 = d->N, np = d->n_final;
     if (2 * np + 2 * (N64 + 1) >= (1ull << 32)) { err = "step 4: too many edges"; return SAGE2OV_ERR_LIMIT; }
     const u32 N = (u32)N64, capH = (u32)(2 * np + 2 * (N64 + 1));
