@@ -52,7 +52,7 @@ def scaling_model(n_unique, n_edges, ms1, ph, alt=None):
     """MODEL, UNMEASURED: the step time on G ranks predicted from the ONE-GPU phase times of this run (no multi-GPU hardware is available to the
     builder; the driver's scaling runs are the measurement).  Per rank: replicated = index build (without the minimiser groups once a rank probes
     fewer than 24 M reads: dev_build_index) + cond half of the reciprocal pass + hit lists / adjacency of the reduce phase + convert; sharded = probe pass,
-    emit half of the reciprocal pass, marks of the reduce phase; exchanges = records (24 B/read), containment planes (2 B/read, all-reduce), edge
+    emit half of the reciprocal pass, marks of the reduce phase; exchanges = records (16 B/read), containment planes (2 B/read, all-reduce), edge
     and survivor buckets (16 B/edge), each rank receiving (G-1)/G of the bytes over G-1 links at `link_efficiency` of one direction of a link,
     plus a fixed latency per collective.  ph: phases of the one-GPU step (ms); alt: index / probe times measured without minimiser groups."""
     eff, lat_ms, ncoll = 0.7, 0.05, 8
@@ -69,7 +69,7 @@ def scaling_model(n_unique, n_edges, ms1, ph, alt=None):
         recip = cond + (ph["reciprocal_ms"] - cond) / G
         marks = ph.get("reduce_marks_ms", 0.0)
         reduce_ = (ph["reduce_ms"] - marks) + marks / G
-        bytes_recv = (24.0 * n_unique + 2 * 2.0 * n_unique + 16.0 * n_edges) * (G - 1) / G
+        bytes_recv = (16.0 * n_unique + 2 * 2.0 * n_unique + 16.0 * n_edges) * (G - 1) / G
         exch = bytes_recv / ((G - 1) * XGMI_LINK_GBS / 2 * eff * 1e9) * 1e3 + ncoll * lat_ms
         t = index + probe + recip + reduce_ + ph["convert_ms"] + exch
         out["ranks"][str(G)] = {"ms": t, "speedup": ms1 / t, "index_ms": index, "probe_ms": probe, "reciprocal_ms": recip, "reduce_ms": reduce_, "convert_ms": ph["convert_ms"],
@@ -417,7 +417,7 @@ def main():
                          # memory-side bytes per launch (PMC, profiles/probe_traffic.json) over the live kernel time: what the kernel really pulls
                          "traffic_achieved": (traffic * share / (kern_ms * 1e-3) / 1e9) if (traffic and kern_ms > 0) else None,
                          "traffic_frac": (traffic * share / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and kern_ms > 0) else None,
-                         "limiter": "instruction issue and latency together: about 830 VALU + 510 scalar wave-instructions per read at SIX waves per SIMD (round 3: 77 VGPRs; four waves left the vector ALUs 71 % busy with every wave waiting on its dependent table and candidate fetches); at this occupancy the candidates of 768 waves per XCD overflow its L2 and the memory-side traffic is x1.5 of the algorithmic bytes, served by the Infinity Cache (DESIGN.md 5.2)",
+                         "limiter": "instruction issue and memory-side line rate together: about 815 VALU + 520 scalar wave-instructions per read at EIGHT waves per SIMD (end of round 3: the sequential-groups form, 64 VGPRs; four waves left the vector ALUs 71 % busy with every wave waiting on its dependent table and candidate fetches); at this occupancy the candidates of 1024 waves per XCD overflow its L2 and the memory-side traffic is x1.76 of the algorithmic bytes = 0.63 of the HBM peak, part of it served by the Infinity Cache (DESIGN.md 5.2)",
                          # a probe pass is up to three launches of the kernel: a sample of 1/128 of the range, the rest (the instantiation the sample picked), and the
                          # few reads the first two listed; kernel_ms and the bytes are those of the whole pass (sum over its launches)
                          "valu": valu,

@@ -196,7 +196,7 @@ int sage2ov_run_steps23(sage2ov_ctx* ctx);
  * Rank r probes read ids [lo_r, hi_r); the reciprocal test reads the neighbours' records
  * (economyGraph.cpp:460), hence the all-gather of fixed-size per-read records, then of edge buckets. */
 int sage2ov_shard_range(const sage2ov_ctx* ctx, uint64_t* lo, uint64_t* hi);          /* ids, hi exclusive */
-int sage2ov_shard_record_bytes(const sage2ov_ctx* ctx, uint64_t* bytes_per_read);     /* 24: right, left, conn|flags */
+int sage2ov_shard_record_bytes(const sage2ov_ctx* ctx, uint64_t* bytes_per_read);     /* 16: right and left extension (position:30, type:2, length:22 each), connection count:18, containment flags:2 */
 int sage2ov_overlap_probe_shard(sage2ov_ctx* ctx);                                    /* kernel only, own range */
 int sage2ov_shard_export_records(sage2ov_ctx* ctx, void* dev_dst, uint64_t max_reads);/* own range -> device buffer */
 int sage2ov_shard_import_records(sage2ov_ctx* ctx, const void* dev_src, uint64_t first_id, uint64_t n_reads);

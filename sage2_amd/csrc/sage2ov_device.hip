@@ -811,17 +811,23 @@ int dev_probe(Device* d, uint64_t lo, uint64_t hi, std::string& err) {
     return 0;
 }
 
-struct Record { u64 right, left; u32 conn, cflag; };
+// The wire form of a read's record, 16 bytes (24 until the end of round 3: the record all-gather is the largest exchange of a multi-GPU step).  Exact because a
+// position is < 2^30 (the context's limit), an extension length < 2^22, the flags are two bits, and the connection count is at most (windows of a read) x (bucket cap
+// of 101 entries, hashTable.cpp:178) < 2^18:   w0 = right pos:30 | type:2 | len:22 | flags:2 | conn[7:0]:8      w1 = left pos:30 | type:2 | len:22 | conn[17:8]:10
+struct Record { u64 w0, w1; };
+__device__ __forceinline__ u64 rec_half(u64 e) { return (e & 0x3FFFFFFFull) | (((e >> 40) & 3ull) << 30) | (((e >> 42) & 0x3FFFFFull) << 32); }
+__device__ __forceinline__ u64 rec_entry(u64 w) { return (w & 0x3FFFFFFFull) | (((w >> 30) & 3ull) << 40) | (((w >> 32) & 0x3FFFFFull) << 42); }
 // (a rank probes a range of POSITIONS of the locality order; since round 3 the per-read arrays are indexed by position too and name neighbours by position --
 //  every rank computes the same order -- so a rank's records are a contiguous slice)
 __global__ void k_pack_records(u64 lo, u64 hi, const u64* right, const u64* left, const u32* conn, const u32* cflag, Record* out) {
     u64 p = lo + (u64)blockIdx.x * blockDim.x + threadIdx.x; if (p >= hi) return;
-    Record r; r.right = right[p]; r.left = left[p]; r.conn = conn[p]; r.cflag = cflag[p]; out[p - lo] = r;
+    const u32 c = min(conn[p], (1u << 18) - 1u), f = cflag[p] & 3u;
+    Record r; r.w0 = rec_half(right[p]) | ((u64)f << 54) | ((u64)(c & 0xFFu) << 56); r.w1 = rec_half(left[p]) | ((u64)(c >> 8) << 54); out[p - lo] = r;
 }
 __global__ void k_unpack_records(u64 first, u64 n, const Record* in, u64* right, u64* left, u32* conn, u32* cflag) {
     u64 x = (u64)blockIdx.x * blockDim.x + threadIdx.x; if (x >= n) return;
-    Record r = in[x]; const u64 p = first + x; right[p] = r.right; left[p] = r.left; conn[p] = r.conn;
-    cflag[p] |= r.cflag;                  // containment marks (economyGraph.cpp:735) are OR-ed, never overwritten: the local probe may have marked this read too
+    Record r = in[x]; const u64 p = first + x; right[p] = rec_entry(r.w0); left[p] = rec_entry(r.w1); conn[p] = (u32)(r.w0 >> 56) | ((u32)(r.w1 >> 54) << 8);
+    cflag[p] |= (u32)(r.w0 >> 54) & 3u;   // containment marks (economyGraph.cpp:735) are OR-ed, never overwritten: the local probe may have marked this read too
 }
 // containment flags travel as two byte planes (bit0 plane, bit1 plane) so that a MAX all-reduce is a bitwise OR
 __global__ void k_flags_export(u64 n, const u32* __restrict__ cflag, uint8_t* out) {

@@ -945,7 +945,7 @@ int sage2ov_shard_range(const sage2ov_ctx* c, uint64_t* lo, uint64_t* hi) {
     const uint64_t N = c->N, w = c->cfg.world, r = c->cfg.rank;
     *lo = 1 + (N * r) / w; *hi = 1 + (N * (r + 1)) / w; return SAGE2OV_OK;
 }
-int sage2ov_shard_record_bytes(const sage2ov_ctx* c, uint64_t* b) { if (!c || !b) return SAGE2OV_ERR_ARG; *b = 24; return SAGE2OV_OK; }
+int sage2ov_shard_record_bytes(const sage2ov_ctx* c, uint64_t* b) { if (!c || !b) return SAGE2OV_ERR_ARG; *b = 16; return SAGE2OV_OK; }
 int sage2ov_overlap_probe_shard(sage2ov_ctx* c) {
     if (!c) return SAGE2OV_ERR_ARG;
     if (!c->indexBuilt) return c->fail(SAGE2OV_ERR_ARG, "build the index first");

@@ -2,7 +2,7 @@
 //
 // One host thread per GPU, each with its own context (rank r of G, include/sage2ov.h: sage2ov_config.rank / world); the read set and the index are
 // replicated, the probe pass is range-partitioned over positions of the locality order, and four one-shot exchanges carry the results:
-//   1. all-gather of the 24-byte per-read records (the reciprocal test reads the NEIGHBOUR's record, economyGraph.cpp:460),
+//   1. all-gather of the 16-byte per-read records (the reciprocal test reads the NEIGHBOUR's record, economyGraph.cpp:460),
 //   2. MAX all-reduce (= OR) of the two containment byte planes (economyGraph.cpp:735: a mark lands on a read of any rank),
 //   3. all-gather of the per-rank edge buckets (counts first, buckets padded to the largest),
 //   4. after the reduce phase, whose marks (economyGraph.cpp:643-707) are sharded over the ranks: all-gather of the per-rank survivor buckets and
@@ -101,17 +101,18 @@ struct Rank {
         const uint64_t N = rs.unique_reads;
         uint64_t maxShard = 0; for (int q = 0; q < S.G; q++) { const uint64_t lo = 1 + N * q / S.G, hi = 1 + N * (q + 1) / S.G; if (hi - lo > maxShard) maxShard = hi - lo; }   // = sage2ov_shard_range of rank q
         DevBuf send, recv, planes, bucket, padded, gathered, all, scratch;
+        uint64_t RB = 0; S2(sage2ov_shard_record_bytes(ctx, &RB));                           // bytes of a read's record on the wire
         // 1. records
-        if (send.need((maxShard ? maxShard : 1) * 24) || recv.need((size_t)S.G * (maxShard ? maxShard : 1) * 24)) return fail("hipMalloc");
+        if (send.need((maxShard ? maxShard : 1) * RB) || recv.need((size_t)S.G * (maxShard ? maxShard : 1) * RB)) return fail("hipMalloc");
         // (on the context's own stream: a hipMemset on the null stream is not ordered with the library's non-blocking stream -- it could land on top of the exported records)
-        if (hipMemsetAsync(send.p, 0, (maxShard ? maxShard : 1) * 24, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return fail("memset");
+        if (hipMemsetAsync(send.p, 0, (maxShard ? maxShard : 1) * RB, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return fail("memset");
         S2(sage2ov_shard_export_records(ctx, send.p, maxShard));
         // 2. containment planes (exported before other ranks' records arrive; the import ORs the flags a record carries)
         uint64_t fb = 0; S2(sage2ov_shard_flags_bytes(ctx, &fb));
         if (planes.need(fb)) return fail("hipMalloc");
         S2(sage2ov_shard_export_flags(ctx, planes.p));
-        if (int rc = allgather(send.p, recv.p, (maxShard ? maxShard : 1) * 24)) return rc;
-        for (int q = 0; q < S.G; q++) { const uint64_t lo = 1 + N * q / S.G, hi = 1 + N * (q + 1) / S.G; if (hi > lo) S2(sage2ov_shard_import_records(ctx, (char*)recv.p + (size_t)q * (maxShard ? maxShard : 1) * 24, lo, hi - lo)); }
+        if (int rc = allgather(send.p, recv.p, (maxShard ? maxShard : 1) * RB)) return rc;
+        for (int q = 0; q < S.G; q++) { const uint64_t lo = 1 + N * q / S.G, hi = 1 + N * (q + 1) / S.G; if (hi > lo) S2(sage2ov_shard_import_records(ctx, (char*)recv.p + (size_t)q * (maxShard ? maxShard : 1) * RB, lo, hi - lo)); }
         if (int rc = allreduce_max_bytes(planes.p, fb)) return rc;
         S2(sage2ov_shard_import_flags(ctx, planes.p));
         S2(sage2ov_overlap_reciprocal(ctx));

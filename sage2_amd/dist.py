@@ -2,7 +2,7 @@
 xGMI on the GPU box, "gloo" in CPU tests).  The read set and the index are replicated; read ids are
 range-partitioned for the probe/verify kernel.  Exchange steps -- all bulk, one-shot:
 
-  1. all-gather of the fixed-size per-read records (right ext, left ext, connections, flags: 24 B/read):
+  1. all-gather of the fixed-size per-read records (right ext, left ext, connections, flags: 16 B/read):
      the reciprocal test reads the NEIGHBOUR's record (economyGraph.cpp:460);
   2. MAX all-reduce (= OR) of the two containment bit planes: a containment mark (economyGraph.cpp:735)
      lands on a read of any rank;
@@ -15,7 +15,7 @@ binds it to a sage2_amd.Context.
 import torch
 import torch.distributed as dist
 
-from .shard import RECORD_BYTES, EDGE_BYTES, shard_range, max_shard  # noqa: F401  (re-exported)
+from .shard import RECORD_BYTES, EDGE_BYTES, shard_range, max_shard, pack_records, unpack_records  # noqa: F401  (re-exported)
 
 
 def _sync(t: torch.Tensor):
@@ -41,7 +41,7 @@ def _all_gather(recv, send, group=None):
 
 
 def allgather_records(send: torch.Tensor, n_unique: int, group=None):
-    """send: uint8 [max_shard*24] holding this rank's records (padded).  Returns a list of (first_id, n, tensor)."""
+    """send: uint8 [max_shard*RECORD_BYTES] holding this rank's records (padded).  Returns a list of (first_id, n, tensor)."""
     world = dist.get_world_size(group)
     recv = torch.empty(world * send.numel(), dtype=torch.uint8, device=send.device)
     _all_gather(recv, send, group)

@@ -1,7 +1,7 @@
 """Read-id range partition of the probe work -- plain Python, no torch: usable from processes that
 only talk to the C ABI.  `sage2_amd.dist` binds these to torch.distributed."""
 
-RECORD_BYTES = 24     # per-read record exchanged between ranks: right ext u64, left ext u64, connections u32, containment flags u32
+RECORD_BYTES = 16     # per-read record exchanged between ranks (sage2ov_shard_record_bytes): right / left extension as position:30 | type:2 | length:22, connections:18, containment flags:2
 EDGE_BYTES = 16       # edge candidate: from u32, to u32, length u32, type u32
 
 
@@ -12,3 +12,25 @@ def shard_range(n_unique, rank, world):
 
 def max_shard(n_unique, world):
     return max(shard_range(n_unique, r, world)[1] - shard_range(n_unique, r, world)[0] for r in range(world))
+
+
+def pack_records(right, left, conn, cflag):
+    """host-side mirror of the wire form (k_pack_records): numpy arrays of one read range -> uint8 [n * RECORD_BYTES].  An extension entry is
+    id-or-position:40 | type:2 | length:22 (economyGraph.h:24-30); on the wire its first field has 30 bits, the connection count 18, the flags 2."""
+    import numpy as np
+    right, left = np.asarray(right, dtype=np.uint64), np.asarray(left, dtype=np.uint64)
+    conn, cflag = np.minimum(np.asarray(conn, dtype=np.uint64), (1 << 18) - 1), np.asarray(cflag, dtype=np.uint64) & np.uint64(3)
+    half = lambda e: (e & np.uint64(0x3FFFFFFF)) | (((e >> np.uint64(40)) & np.uint64(3)) << np.uint64(30)) | (((e >> np.uint64(42)) & np.uint64(0x3FFFFF)) << np.uint64(32))
+    w = np.empty((len(right), 2), dtype="<u8")
+    w[:, 0] = half(right) | (cflag << np.uint64(54)) | ((conn & np.uint64(0xFF)) << np.uint64(56))
+    w[:, 1] = half(left) | ((conn >> np.uint64(8)) << np.uint64(54))
+    return w.reshape(-1).view(np.uint8)
+
+
+def unpack_records(buf):
+    """uint8 [n * RECORD_BYTES] -> (right, left, conn, cflag), the inverse of pack_records (k_unpack_records)"""
+    import numpy as np
+    w = np.frombuffer(bytes(buf), dtype="<u8").reshape(-1, 2)
+    entry = lambda x: (x & np.uint64(0x3FFFFFFF)) | (((x >> np.uint64(30)) & np.uint64(3)) << np.uint64(40)) | (((x >> np.uint64(32)) & np.uint64(0x3FFFFF)) << np.uint64(42))
+    conn = ((w[:, 0] >> np.uint64(56)) | ((w[:, 1] >> np.uint64(54)) << np.uint64(8))).astype(np.uint32)
+    return entry(w[:, 0]), entry(w[:, 1]), conn, ((w[:, 0] >> np.uint64(54)) & np.uint64(3)).astype(np.uint32)

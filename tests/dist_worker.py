@@ -29,17 +29,19 @@ def main():
     # the union of all shard ranges is exactly 1..n
     ranges = [sd.shard_range(n, r, world) for r in range(world)]
     assert ranges[0][0] == 1 and ranges[-1][1] == n + 1 and all(ranges[r][1] == ranges[r + 1][0] for r in range(world - 1))
-    # ---- 1. per-read records (24 B: right u64, left u64, conn u32, cflag u32), own range only
-    rec = np.zeros(n + 1, dtype=[("right", "<u8"), ("left", "<u8"), ("conn", "<u4"), ("cflag", "<u4")])
-    rec["right"], rec["left"], rec["conn"] = right, left, conn
+    # ---- 1. per-read records (RECORD_BYTES: right / left extension, connections, containment flags), own range only
+    cflag = (np.arange(n + 1) * 7 + 1) % 4                  # (the oracle keeps containment in the status; any two bits must survive the wire)
     ms = sd.max_shard(n, world)
     send = torch.zeros(ms * sd.RECORD_BYTES, dtype=torch.uint8)
-    mine = torch.from_numpy(rec[lo:hi].view(np.uint8).copy())
+    mine = torch.from_numpy(sd.pack_records(right[lo:hi], left[lo:hi], conn[lo:hi], cflag[lo:hi]).copy())
+    assert mine.numel() == (hi - lo) * sd.RECORD_BYTES
     send[: mine.numel()] = mine
-    got = np.zeros(n + 1, dtype=rec.dtype)
+    got = [np.zeros(n + 1, dtype=np.uint64), np.zeros(n + 1, dtype=np.uint64), np.zeros(n + 1, dtype=np.uint32), np.zeros(n + 1, dtype=np.uint32)]
     for first, cnt, t in sd.allgather_records(send, n):
-        got[first:first + cnt] = np.frombuffer(t.numpy().tobytes(), dtype=rec.dtype)
-    assert np.array_equal(got[1:], rec[1:]), "record all-gather does not reassemble the full table"
+        for a, b in zip(got, sd.unpack_records(t.numpy().tobytes())):
+            a[first:first + cnt] = b
+    assert np.array_equal(got[0][1:], np.asarray(right, dtype=np.uint64)[1:]) and np.array_equal(got[1][1:], np.asarray(left, dtype=np.uint64)[1:]), "record all-gather does not reassemble the extensions"
+    assert np.array_equal(got[2][1:], np.asarray(conn, dtype=np.uint32)[1:]) and np.array_equal(got[3][1:], cflag[1:].astype(np.uint32)), "record all-gather loses connections or flags"
     # ---- 2. containment bit planes: every rank marks only what ITS reads contain -> OR over ranks
     is6 = (status == 6)
     planes = np.zeros(2 * (n + 1), dtype=np.uint8)
