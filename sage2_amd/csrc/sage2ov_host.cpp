@@ -787,8 +787,80 @@ int sage2ov_reads_save(sage2ov_ctx* c, const char* path) {                      
     });
     fclose(f); return rc;
 }
+// P.reads as the writers produce it (readLoader.cpp:29-36: "frequency TAB length TAB read TAB reverse complement NL" per read, N on the first line), mapped and
+// parsed by all I/O threads: a first pass over line-aligned chunks counts the lines and finds the longest read, a second packs every read straight into its slot
+// (eight bases per step, pack8).  1: loaded.  0: the file is not strictly of that shape (other separators, CRLF, a sequence whose length differs from its length
+// field, a wrong line count, ...) -- the fscanf reader below then takes it, with the reference's token semantics.  < 0: error.
+static int reads_load_parallel(sage2ov_ctx* c, const char* path) {
+    const int fd = ::open(path, O_RDONLY); if (fd < 0) return 0;
+    struct stat sb; if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode) || sb.st_size < 4) { ::close(fd); return 0; }
+    const size_t size = (size_t)sb.st_size;
+    const char* m = (const char*)mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0); ::close(fd);
+    if (m == MAP_FAILED) return 0;
+    struct Unmap { const char* p; size_t n; ~Unmap() { munmap((void*)p, n); } } um{m, size};
+    madvise((void*)m, size, MADV_SEQUENTIAL);
+    size_t h = 0; uint64_t N = 0; while (h < size && m[h] >= '0' && m[h] <= '9' && h < 19) N = N * 10 + (uint64_t)(m[h++] - '0');
+    if (h == 0 || h >= size || m[h] != '\n') return 0;
+    h++;
+    if (N >= (1ull << 32) || m[size - 1] != '\n') return 0;
+    const int nt = io_threads(c); const size_t nchunks = (size_t)nt * 4;
+    std::vector<size_t> cut(nchunks + 1); cut[0] = h; cut[nchunks] = size;
+    for (size_t x = 1; x < nchunks; x++) { size_t p = h + (size - h) / nchunks * x; if (p < cut[x - 1]) p = cut[x - 1]; const char* nl = (const char*)memchr(m + p, '\n', size - p); cut[x] = nl ? (size_t)(nl - m) + 1 : size; }
+    // one line: digits TAB digits TAB <len> characters TAB ... NL; returns the position behind the line, 0 when the line is not of that shape
+    auto line = [&](size_t p, size_t e, uint64_t& fr, uint64_t& L, size_t& sq) -> size_t {
+        size_t q = p; fr = 0; while (q < e && m[q] >= '0' && m[q] <= '9' && q - p < 10) fr = fr * 10 + (uint64_t)(m[q++] - '0');
+        if (q == p || q >= e || m[q] != '\t') return 0;
+        const size_t p2 = ++q; L = 0; while (q < e && m[q] >= '0' && m[q] <= '9' && q - p2 < 7) L = L * 10 + (uint64_t)(m[q++] - '0');
+        if (q == p2 || q >= e || m[q] != '\t') return 0;
+        sq = ++q; if (sq + L >= e || m[sq + L] != '\t') return 0;
+        const char* nl = (const char*)memchr(m + sq + L + 1, '\n', e - (sq + L + 1)); if (!nl) return 0;
+        return (size_t)(nl - m) + 1;
+    };
+    std::vector<uint64_t> cnt(nchunks + 1, 0); std::vector<int> mx(nchunks, 0); bool bad = false;
+    #pragma omp parallel for num_threads(nt) schedule(dynamic, 1)
+    for (int64_t x = 0; x < (int64_t)nchunks; x++) {
+        size_t p = cut[x]; const size_t e = cut[x + 1]; uint64_t n = 0, fr, L; size_t sq; int ml = 0;
+        while (p < e) {
+            const size_t nx = line(p, e, fr, L, sq);
+            bool ws = false; if (nx) for (size_t i = 0; i < L; i++) ws |= (unsigned char)m[sq + i] <= ' ';
+            if (!nx || ws || L > 1018) {
+                #pragma omp atomic write
+                bad = true;
+                break;
+            }
+            ml = std::max(ml, (int)L); n++; p = nx;
+        }
+        cnt[x + 1] = n; mx[x] = ml;
+    }
+    if (bad) return 0;
+    int maxL = 0; for (size_t x = 0; x < nchunks; x++) { cnt[x + 1] += cnt[x]; maxL = std::max(maxL, mx[x]); }
+    if (cnt[nchunks] != N) return 0;
+    c->maxL = maxL; c->S = choose_S(std::max(maxL, 1)); const int S = c->S;
+    c->N = N; c->words.resize((N + 1) * S); c->len.resize(N + 1); c->freq.resize(N + 1);
+    for (int q = 0; q < S; q++) c->words[q] = 0;
+    c->len[0] = 0; c->freq[0] = 0;
+    #pragma omp parallel for num_threads(nt) schedule(dynamic, 1)
+    for (int64_t x = 0; x < (int64_t)nchunks; x++) {
+        size_t p = cut[x]; const size_t e = cut[x + 1]; uint64_t i = cnt[x] + 1, fr, L; size_t sq;
+        while (p < e) {
+            p = line(p, e, fr, L, sq);
+            uint64_t* w = &c->words[i * S]; for (int q = 0; q < S; q++) w[q] = 0;
+            const char* b = m + sq; int y = 0;
+            for (; y + 8 <= (int)L; y += 8) {
+                uint64_t v, o; memcpy(&v, b + y, 8);
+                if (!pack8(v, o)) { o = 0; for (int z = 0; z < 8; z++) { uint8_t cd = g_code[(unsigned char)b[y + z]]; if (cd > 3) cd = 0; o |= (uint64_t)cd << (14 - 2 * z); } }   // (anything but ACGT reads as A, like the loop below)
+                w[y >> 5] |= o << (48 - 2 * (y & 31));
+            }
+            for (; y < (int)L; y++) { uint8_t cd = g_code[(unsigned char)b[y]]; if (cd > 3) cd = 0; w[y >> 5] |= (uint64_t)cd << (62 - 2 * (y & 31)); }
+            w[S - 1] |= L; c->len[i] = (uint16_t)L; c->freq[i] = (uint16_t)(unsigned)fr;
+            i++;
+        }
+    }
+    return 1;
+}
 int sage2ov_reads_load(sage2ov_ctx* c, const char* path) {                            // readLoader.cpp:289-307, :38-48
     if (!c || !path) return SAGE2OV_ERR_ARG;
+    if (!getenv("SAGE2OV_SEQUENTIAL_READER")) { const int pr = reads_load_parallel(c, path); if (pr < 0) return pr; if (pr == 1) { c->organized = false; return upload(c); } }
     FILE* f = fopen(path, "r"); if (!f) return c->fail(SAGE2OV_ERR_IO, std::string("cannot open ") + path);
     unsigned long long N = 0; if (fscanf(f, "%llu", &N) != 1) { fclose(f); return c->fail(SAGE2OV_ERR_IO, "bad .reads header"); }
     std::vector<std::string> seqs(N + 1); std::vector<unsigned> fr(N + 1), ln(N + 1); int maxL = 0;

@@ -199,6 +199,39 @@ def test_parallel_file_reader_equals_sequential_reader(form, tmp_path, monkeypat
     assert np.array_equal(pa, pb) and np.array_equal(la, lb) and np.array_equal(fa, fb)
 
 
+@pytest.mark.parametrize("form", ["as_written", "lower_case_and_n", "crlf", "spaces", "short_sequence", "wrong_count"])
+def test_parallel_reads_file_loader_equals_fscanf_loader(form, tmp_path, monkeypatch):
+    """P.reads (readLoader.cpp:289-307) is mapped and parsed by all threads when it is strictly of the shape the writers produce (reads_load_parallel);
+    any other shape -- CRLF, blanks as separators, a sequence shorter than its length field, a line count that differs from the header -- goes to the
+    fscanf reader with the reference's token semantics.  Same store either way."""
+    rng = np.random.default_rng(5)
+    n = 3000
+    recs = []
+    for i in range(n):
+        L = int(rng.integers(41, 151)); sq = "".join(rng.choice(list("ACGT"), size=L))
+        if form == "lower_case_and_n" and i % 7 == 3:
+            sq = sq[:9].lower() + "N" + sq[10:]
+        recs.append((int(rng.integers(1, 70000)), L, sq))
+    path = str(tmp_path / "t.reads"); sep, nl = ("  " if form == "spaces" else "\t"), ("\r\n" if form == "crlf" else "\n")
+    with open(path, "w", newline="") as f:
+        f.write(f"{n - 1 if form == 'wrong_count' else n}{nl}")
+        for i, (fr, L, sq) in enumerate(recs):
+            body = sq[:-5] if form == "short_sequence" and i == n // 2 else sq
+            f.write(f"{fr}{sep}{L}{sep}{body}{sep}{body[::-1]}{nl}")
+    def load(sequential):
+        if sequential:
+            monkeypatch.setenv("SAGE2OV_SEQUENTIAL_READER", "1")
+        else:
+            monkeypatch.delenv("SAGE2OV_SEQUENTIAL_READER", raising=False)
+        c = s2.Context(21, device=-2); c.reads_load(path); out = c.reads_export(); nu = c.reads_stats().unique_reads; c.close()
+        return out, nu
+    (pa, la, fa), na = load(False)
+    (pb, lb, fb), nb = load(True)
+    assert na == nb == (n - 1 if form == "wrong_count" else n)
+    assert np.array_equal(pa, pb) and np.array_equal(la, lb) and np.array_equal(fa, fb)
+    assert [int(x) for x in la[1:4]] == [r[1] for r in recs[:3]] and [int(x) for x in fa[1:4]] == [r[0] & 0xFFFF for r in recs[:3]]
+
+
 def test_step4_needs_the_gpu():
     """no CPU fallback: a context without a device refuses steps 2-4 (here: step 4 and the edge import) with SAGE2OV_ERR_DEVICE"""
     ctx = s2.Context(21, device=-2)
