@@ -262,7 +262,8 @@ struct SeqFile {
 // the line two below starts with '+', and every chunk is parsed strictly as four-line records (equal sequence and quality lengths).
 // Anything else -- multi-line FASTQ, a file that is neither, a chunk that does not parse -- returns false and the sequential reader
 // below takes the whole file.
-static bool add_plain_file_parallel(sage2ov_ctx* c, const char* path) {
+struct StagePart { RawU64 pool, off; RawU16 lens; uint64_t good = 0, bp = 0, small = 0, records = 0; };      // what one thread staged
+static bool parse_plain_file_parallel(sage2ov_ctx* c, const char* path, std::vector<StagePart>& parts) {
     const int fd = ::open(path, O_RDONLY); if (fd < 0) return false;
     struct stat sb; if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode) || sb.st_size < (1 << 20)) { ::close(fd); return false; }
     const size_t size = (size_t)sb.st_size;
@@ -289,8 +290,8 @@ static bool add_plain_file_parallel(sage2ov_ctx* c, const char* path) {
     const size_t nchunks = std::max<size_t>((size_t)nt, std::min<size_t>(4096, size >> 24));
     std::vector<size_t> cut(nchunks + 1); cut[0] = 0; cut[nchunks] = size;
     for (size_t x = 1; x < nchunks; x++) cut[x] = std::max(cut[x - 1], boundary((size * x) / nchunks));
-    struct Part { RawU64 pool, off; RawU16 lens; uint64_t good = 0, bp = 0, small = 0, records = 0; };
-    std::vector<Part> parts(nt); bool bad = false;
+    using Part = StagePart;
+    parts.clear(); parts.resize(nt); bool bad = false;
     #pragma omp parallel num_threads(nt)
     {
         Part& P = parts[omp_get_thread_num()]; std::string seq; std::vector<uint8_t> codes;
@@ -334,7 +335,11 @@ static bool add_plain_file_parallel(sage2ov_ctx* c, const char* path) {
     }
     if (bad) return false;
     lap("split + filter + pack (threads)");
-    // the threads' pools, one behind the other (each thread copies its own: the arrays are sized without being written)
+    return true;
+}
+// the threads' pools, one behind the other at the end of the context's staging arrays (each thread copies its own: the arrays are sized without being written)
+static void commit_parts(sage2ov_ctx* c, std::vector<StagePart>& parts) {
+    using Part = StagePart; const int nt = (int)parts.size(); HostLap lap("input");
     std::vector<uint64_t> wordBase(nt + 1), readBase(nt + 1); wordBase[0] = c->pool.size(); readBase[0] = c->poolOff.size();
     for (int t = 0; t < nt; t++) { wordBase[t + 1] = wordBase[t] + parts[t].pool.size(); readBase[t + 1] = readBase[t] + parts[t].off.size(); }
     c->pool.resize(wordBase[nt]); c->poolOff.resize(readBase[nt]); c->poolLen.resize(readBase[nt]);
@@ -349,12 +354,24 @@ static bool add_plain_file_parallel(sage2ov_ctx* c, const char* path) {
     }
     for (Part& P : parts) { c->goodReads += P.good; c->totalBP += P.bp; c->smallReads += P.small; c->totalReads += P.records; }
     lap("concatenation of the threads' pools");
-    return true;
+}
+static bool add_plain_file_parallel(sage2ov_ctx* c, const char* path) {
+    std::vector<StagePart> parts; if (!parse_plain_file_parallel(c, path, parts)) return false;
+    commit_parts(c, parts); return true;
+}
+// Two mate files are read alternately, file 1 first, until the file whose turn it is has no record left (inputReader.cpp:26-49): with n1 = n2 or n1 = n2 + 1 records
+// that is every record of both files, and since the ids are ranks after the sort the order they are staged in is free -- both files then go through the parallel
+// reader one after the other.  Any other pair of counts (or a file the parallel reader does not take) is the sequential reader's business.
+static bool add_mate_files_parallel(sage2ov_ctx* c, const char* p1, const char* p2) {
+    std::vector<StagePart> a, b; if (!parse_plain_file_parallel(c, p1, a) || !parse_plain_file_parallel(c, p2, b)) return false;
+    uint64_t n1 = 0, n2 = 0; for (auto& P : a) n1 += P.records; for (auto& P : b) n2 += P.records;
+    if (n1 != n2 && n1 != n2 + 1) return false;
+    commit_parts(c, a); commit_parts(c, b); return true;
 }
 
 // records are split sequentially (cheap: memchr), filtered and packed by all threads in batches
 int add_files(sage2ov_ctx* c, const char* p1, const char* p2) {
-    if (!(p2 && *p2) && !getenv("SAGE2OV_SEQUENTIAL_READER") && add_plain_file_parallel(c, p1)) return SAGE2OV_OK;
+    if (!getenv("SAGE2OV_SEQUENTIAL_READER") && ((p2 && *p2) ? add_mate_files_parallel(c, p1, p2) : add_plain_file_parallel(c, p1))) return SAGE2OV_OK;
     SeqFile f1, f2; if (!f1.open(p1)) return c->fail(SAGE2OV_ERR_IO, std::string("cannot open ") + p1);
     const bool two = p2 && *p2; if (two && !f2.open(p2)) return c->fail(SAGE2OV_ERR_IO, std::string("cannot open ") + p2);
     const int nt = io_threads(c);

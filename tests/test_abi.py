@@ -199,6 +199,35 @@ def test_parallel_file_reader_equals_sequential_reader(form, tmp_path, monkeypat
     assert np.array_equal(pa, pb) and np.array_equal(la, lb) and np.array_equal(fa, fb)
 
 
+@pytest.mark.parametrize("extra1,extra2", [(0, 0), (1, 0), (2, 0), (0, 3)])
+def test_parallel_reader_of_two_mate_files_equals_alternating_reader(extra1, extra2, tmp_path, monkeypatch):
+    """mate files are read alternately until the file whose turn it is runs out (inputReader.cpp:26-49); with n1 = n2 or n2 + 1 records that is everything, and
+    both files go through the parallel reader (add_mate_files_parallel) -- any other pair of counts stays with the sequential reader, which drops the surplus.
+    Same read set and counters either way."""
+    rng = np.random.default_rng(11)
+    n, L = 12000, 100
+    def write(path, cnt, tag):
+        with open(path, "w") as f:
+            for i in range(cnt):
+                f.write(f">{tag}{i}\n{''.join(rng.choice(list('ACGT'), size=L - int(rng.integers(0, 20))))}\n")
+    p1, p2 = str(tmp_path / "a_1.fa"), str(tmp_path / "a_2.fa")
+    write(p1, n + extra1, "a"); write(p2, n + extra2, "b")
+    assert os.path.getsize(p1) > (1 << 20) and os.path.getsize(p2) > (1 << 20)
+    def load(sequential):
+        if sequential:
+            monkeypatch.setenv("SAGE2OV_SEQUENTIAL_READER", "1")
+        else:
+            monkeypatch.delenv("SAGE2OV_SEQUENTIAL_READER", raising=False)
+        c = s2.Context(21, device=-2); c.reads_add_file(p1, p2); c.reads_organize()
+        st = c.reads_stats(); out = c.reads_export(); c.close()
+        return out, (st.total_reads, st.good_reads, st.unique_reads, st.total_bp)
+    (pa, la, fa), sa = load(False)
+    (pb, lb, fb), sb = load(True)
+    expect = 2 * n + (1 if extra1 == 1 else 0) if extra2 == 0 and extra1 <= 1 else (2 * n + 1 if extra1 >= 1 else 2 * n)
+    assert sa == sb and sa[0] == expect
+    assert np.array_equal(pa, pb) and np.array_equal(la, lb) and np.array_equal(fa, fb)
+
+
 @pytest.mark.parametrize("form", ["as_written", "lower_case_and_n", "crlf", "spaces", "short_sequence", "wrong_count"])
 def test_parallel_reads_file_loader_equals_fscanf_loader(form, tmp_path, monkeypatch):
     """P.reads (readLoader.cpp:289-307) is mapped and parsed by all threads when it is strictly of the shape the writers produce (reads_load_parallel);
