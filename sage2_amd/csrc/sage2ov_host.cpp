@@ -1206,8 +1206,65 @@ int sage2ov_edges_import(sage2ov_ctx* c, const sage2ov_edge* e, uint64_t n) {
     return SAGE2OV_OK;
 }
 // loadOverlapGraphFromFile (overlapGraph.cpp:371-442) for the graph step 3 writes: simple edges only (list size 0)
+// P.graph3 as the writers produce it (overlapGraph.cpp:338-369, :12-20: three header lines, then per edge the record "from TAB to TAB type TAB 1 TAB length TAB 0 TAB 0",
+// an empty line, the twin's record, an empty line), mapped and parsed by all I/O threads: a first pass over line-aligned chunks counts the record lines, which tells
+// every chunk whether it starts at an edge or at a twin; the second parses edge + twin pairs (the owner of an edge reads its twin past the chunk's end).
+// 1: edges filled.  0: not strictly that shape (the parser below then takes the file, with its own diagnostics).
+static int graph_load_parallel(sage2ov_ctx* c, const char* path, std::vector<sage2ov_edge>& edges, unsigned long long& nr, unsigned long long& avg) {
+    const int fd = ::open(path, O_RDONLY); if (fd < 0) return 0;
+    struct stat sb; if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode) || sb.st_size < 8) { ::close(fd); return 0; }
+    const size_t size = (size_t)sb.st_size;
+    const char* m = (const char*)mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0); ::close(fd);
+    if (m == MAP_FAILED) return 0;
+    struct Unmap { const char* p; size_t n; ~Unmap() { munmap((void*)p, n); } } um{m, size};
+    if (m[size - 1] != '\n') return 0;
+    auto num = [&](size_t& p, size_t e, unsigned long long& v) -> bool { const size_t p0 = p; v = 0; while (p < e && m[p] >= '0' && m[p] <= '9' && p - p0 < 19) v = v * 10 + (unsigned long long)(m[p++] - '0'); return p > p0; };
+    size_t h = 0; unsigned long long hd[3];
+    for (int x = 0; x < 3; x++) { if (!num(h, size, hd[x]) || h >= size || m[h] != '\n') return 0; h++; }
+    nr = hd[1]; avg = hd[2];
+    // a record line + its empty line; v: from, to, type, 1, length, flow, list size.  Returns the position behind the empty line, 0 when the lines are not of that shape
+    auto record = [&](size_t p, size_t e, unsigned long long* v) -> size_t {
+        for (int x = 0; x < 7; x++) { if (!num(p, e, v[x]) || p >= e || m[p] != (x < 6 ? '\t' : '\n')) return 0; p++; }
+        if (p >= e || m[p] != '\n') return 0;
+        return p + 1;
+    };
+    const int nt = io_threads(c); const size_t nchunks = (size_t)nt * 4;
+    std::vector<size_t> cut(nchunks + 1); cut[0] = h; cut[nchunks] = size;
+    for (size_t x = 1; x < nchunks; x++) {            // cut behind an empty line (i.e. at the start of a record line)
+        size_t p = std::max(cut[x - 1], h + (size - h) / nchunks * x);
+        for (;;) { const char* nl = p < size ? (const char*)memchr(m + p, '\n', size - p) : nullptr; if (!nl || (size_t)(nl - m) + 1 >= size) { p = size; break; } p = (size_t)(nl - m) + 1; if (m[p] == '\n') { p++; break; } }
+        cut[x] = std::max(p, cut[x - 1]);
+    }
+    std::vector<uint64_t> cnt(nchunks + 1, 0); bool bad = false;
+    #pragma omp parallel for num_threads(nt) schedule(dynamic, 1)
+    for (int64_t x = 0; x < (int64_t)nchunks; x++) {
+        size_t p = cut[x]; const size_t e = cut[x + 1]; uint64_t n = 0; unsigned long long v[7];
+        while (p < e) { p = record(p, e, v); if (!p || v[6] != 0) { bad = true; break; } n++; }      // (benign race: only ever set)
+        cnt[x + 1] = n;
+    }
+    if (bad) return 0;
+    for (size_t x = 0; x < nchunks; x++) cnt[x + 1] += cnt[x];
+    if (cnt[nchunks] & 1) return 0;
+    edges.resize(cnt[nchunks] / 2);
+    #pragma omp parallel for num_threads(nt) schedule(dynamic, 1)
+    for (int64_t x = 0; x < (int64_t)nchunks; x++) {
+        size_t p = cut[x]; const size_t e = cut[x + 1]; uint64_t r = cnt[x]; unsigned long long a[7], b[7];
+        if (p < e && (r & 1)) { p = record(p, size, a); r++; }                                       // a twin: its edge belongs to the chunk before
+        while (p < e) {
+            p = record(p, size, a); const size_t q = record(p, size, b);
+            if (!q || a[0] != b[1] || a[1] != b[0]) { bad = true; break; }
+            sage2ov_edge o{}; o.from = a[0]; o.to = a[1]; o.type = (uint8_t)a[2]; o.length = (uint32_t)a[4]; o.length_twin = (uint32_t)b[4];
+            edges[r / 2] = o; r += 2; p = q;
+        }
+    }
+    return bad ? 0 : 1;
+}
 int sage2ov_graph_load(sage2ov_ctx* c, const char* path) {
     if (!c || !path) return SAGE2OV_ERR_ARG;
+    if (!getenv("SAGE2OV_SEQUENTIAL_READER")) {
+        std::vector<sage2ov_edge> pe; unsigned long long pnr = 0, pavg = 0;
+        if (graph_load_parallel(c, path, pe, pnr, pavg) == 1) { c->goodReads = pnr; c->totalBP = pavg * pnr; return sage2ov_edges_import(c, pe.data(), pe.size()); }
+    }
     FILE* f = fopen(path, "rb"); if (!f) return c->fail(SAGE2OV_ERR_IO, std::string("cannot open ") + path);
     std::string txt; { char buf[1 << 16]; size_t n; while ((n = fread(buf, 1, sizeof buf, f)) > 0) txt.append(buf, n); } fclose(f);
     const char* p = txt.c_str(); const char* end = p + txt.size();

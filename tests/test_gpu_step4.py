@@ -1,7 +1,7 @@
 """GPU: step 4 (graph simplification on the device, through the C ABI) against the graphs the reference's own classes hold after their
 step 4 (tests/golden/*.graph4.gz, dumped by oracle/ref_driver.cpp::sage2ref_run_step4) and against the CPU restatement
 (oracle/step4_oracle.cpp) on larger inputs: byte identity of the written file -- edges, read lists and their order."""
-import ctypes, gzip, json, os
+import ctypes, gzip, json, os, shutil
 import numpy as np
 import pytest
 import fixtures as fx
@@ -106,6 +106,14 @@ def test_cli_steps_1_to_4_and_restart_at_4(tmp_path):
     assert open(os.path.join(out, "t.graph4"), "rb").read() == want
     subprocess.run([exe, "-k", str(m["k"]), "-o", out, "-p", "u", "-i", "t", "-m", "4", "-M", "4"], check=True, stdout=subprocess.DEVNULL)
     assert open(os.path.join(out, "u.graph4"), "rb").read() == want
+    # the restart reads P.reads and P.graph3 with the mapped, chunk-parallel loaders; the one-thread loaders (SAGE2OV_SEQUENTIAL_READER) give the same file
+    subprocess.run([exe, "-k", str(m["k"]), "-o", out, "-p", "w", "-i", "t", "-m", "4", "-M", "4"], check=True, stdout=subprocess.DEVNULL, env=dict(os.environ, SAGE2OV_SEQUENTIAL_READER="1"))
+    assert open(os.path.join(out, "w.graph4"), "rb").read() == want
+    # a P.graph3 that is not strictly of the writers' shape (blanks instead of tabs) still loads: the general parser takes it
+    txt = open(os.path.join(out, "t.graph3")).read().replace("\t", " ")
+    open(os.path.join(out, "b.graph3"), "w").write(txt); shutil.copy(os.path.join(out, "t.reads"), os.path.join(out, "b.reads"))
+    subprocess.run([exe, "-k", str(m["k"]), "-o", out, "-p", "x", "-i", "b", "-m", "4", "-M", "4"], check=True, stdout=subprocess.DEVNULL)
+    assert open(os.path.join(out, "x.graph4"), "rb").read() == want
 
 
 def test_plain_jumping_path_equals_splitter_ranking(monkeypatch, tmp_path):
