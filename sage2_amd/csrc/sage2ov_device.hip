@@ -477,7 +477,7 @@ int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t
         // worst case (every tuple in one window), big ones an eighth of it
         { const u64 whCap = n <= (64u << 20) ? nAlloc : nAlloc / 8; WS(whs, u64, WS_WHERE, whCap); A.wh = whs; A.wh_cap = whCap; }
         static const u64 ixPerCu = getenv("SAGE2OV_IXW_GRID_PER_CU") ? std::max(1, atoi(getenv("SAGE2OV_IXW_GRID_PER_CU"))) : 6;
-        hipLaunchKernelGGL(k_ix_window, dim3((unsigned)std::min<u64>(nW, 256ull * ixPerCu)), dim3(256), 0, d->stream, A);      // persistent: two rounds of 3 workgroups per CU, each with ONE pair of statistics atomics
+        hipLaunchKernelGGL(k_ix_window, dim3((unsigned)std::min<u64>(nW, 256ull * ixPerCu)), dim3(IXW_T), 0, d->stream, A);      // persistent: two rounds of 3 workgroups per CU, each with ONE pair of statistics atomics
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(c, d->d_counters + 8, sizeof c, hipMemcpyDeviceToHost, d->stream));
         u64 c9 = 0; HIPCHK(hipMemcpyAsync(&c9, d->d_counters + 8 + 9, sizeof c9, hipMemcpyDeviceToHost, d->stream));
