@@ -328,7 +328,8 @@ static bool parse_plain_file_parallel(sage2ov_ctx* c, const char* path, std::vec
                         bad = true;
                         break;
                     }
-                    stage(m + l1, ns); p = l4;
+                    if (stage_ascii(c, m + l1, ns, P.pool, P.off, P.lens, P.good, P.bp, P.small) < 0) stage(m + l1, ns); else P.records++;     // (eight bases per step; longer than the 32-word layout: the table form)
+                    p = l4;
                 }
             }
         }
