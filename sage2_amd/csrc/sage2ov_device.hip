@@ -571,11 +571,14 @@ static int scan_u32(Device* d, const u32* in, u64 n, u32* out, u64* total, std::
 // processing order of ids [lo,hi): grouped by the reads' global minimiser (see k_minimizer)
 static int build_locality_order(Device* d, u64 lo, u64 hi, const u32** order_out, std::string& err) {
     const u64 n = hi - lo;
-    // reads sorted by (top bits of their global minimiser's hash, strand of the minimiser, start of the read relative to it): LSD radix passes
-    // (kernels_partition.inc), first the 9 bits of strand + offset, then 27 bits of the hash (three passes) -- reads with one minimiser end up next to each
+    // reads sorted by (their global minimiser's hash, strand of the minimiser, start of the read relative to it): LSD radix passes
+    // (kernels_partition.inc), first the 9 bits of strand + offset, then the hash -- reads with one minimiser end up next to each
     // other, each starting a few bases after the one before.  Measured at BASELINE configs[2]: probe kernel 149 -> 142 ms from the finer processing
     // order alone, 120 ms with the read store in that order too.  *order_out: per position, meta << 32 | id.
-    int lg = 27;
+    // ALL 32 bits of the hash since the end of round 3 (four passes of 8 bits; 27 bits = three passes of 9 before): two minimisers that share a bucket interleave
+    // their reads and break each other's runs of shifted reads (window reuse, 5.2) -- hash bits -> probe pass at configs[2]: 18 -> 97.2 ms, 24 -> 78.8, 27 -> 62.5,
+    // 30 -> 57.2, 32 -> 56.5, for 0.3 ms more of index build.
+    int lg = 32;
     if (const char* ev = getenv("SAGE2OV_ORDER_BITS")) lg = std::max(1, std::min(32, atoi(ev)));
     const u32 ntiles = (u32)((n + PT_TILE - 1) / PT_TILE);
     PtBufs B; B.W = 3;                                                        // {hash, id, meta}
