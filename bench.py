@@ -50,8 +50,8 @@ XGMI_LINK_GBS = 153.0          # MI355X_MICROARCH.md / task notes: 7 xGMI links 
 
 def scaling_model(n_unique, n_edges, ms1, ph, alt=None):
     """MODEL, UNMEASURED: the step time on G ranks predicted from the ONE-GPU phase times of this run (no multi-GPU hardware is available to the
-    builder; the driver's scaling runs are the measurement).  Per rank: replicated = index build (without the minimiser groups once
-    (N - 8 M) / 10.5 M / G < 1, the library's rule: dev_build_index) + cond half of the reciprocal pass + hit lists / adjacency of the reduce phase + convert; sharded = probe pass,
+    builder; the driver's scaling runs are the measurement).  Per rank: replicated = index build (without the minimiser groups below
+    100 M reads per rank, the library's rule: dev_build_index) + cond half of the reciprocal pass + hit lists / adjacency of the reduce phase + convert; sharded = probe pass,
     emit half of the reciprocal pass, marks of the reduce phase; exchanges = records (16 B/read), containment planes (2 B/read, all-reduce), edge
     and survivor buckets (16 B/edge), each rank receiving (G-1)/G of the bytes over G-1 links at `link_efficiency` of one direction of a link,
     plus a fixed latency per collective.  ph: phases of the one-GPU step (ms); alt: index / probe times measured without minimiser groups."""
@@ -62,7 +62,7 @@ def scaling_model(n_unique, n_edges, ms1, ph, alt=None):
                                                          "sharded": "probe pass, emit half of the reciprocal pass, marks of the reduce phase"},
            "one_gpu_ms": ms1, "ranks": {}}
     for G in (2, 4, 8):
-        groups = (n_unique - 8e6) / G >= 10.5e6
+        groups = n_unique / G >= 100e6
         index = ph["index_ms"] if (groups or not alt) else alt["index_ms"]
         probe = (ph["probe_ms"] if (groups or not alt) else alt["probe_ms"]) / G
         cond = ph.get("reciprocal_cond_ms", ph["reciprocal_ms"])
@@ -417,7 +417,7 @@ def main():
                          # memory-side bytes per launch (PMC, profiles/probe_traffic.json) over the live kernel time: what the kernel really pulls
                          "traffic_achieved": (traffic * share / (kern_ms * 1e-3) / 1e9) if (traffic and kern_ms > 0) else None,
                          "traffic_frac": (traffic * share / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and kern_ms > 0) else None,
-                         "limiter": "instruction issue and memory-side line rate together: about 815 VALU + 520 scalar wave-instructions per read at EIGHT waves per SIMD (end of round 3: the sequential-groups form, 64 VGPRs; four waves left the vector ALUs 71 % busy with every wave waiting on its dependent table and candidate fetches); at this occupancy the candidates of 1024 waves per XCD overflow its L2 and the memory-side traffic is x1.76 of the algorithmic bytes = 0.63 of the HBM peak, part of it served by the Infinity Cache (DESIGN.md 5.2)",
+                         "limiter": "memory-side line rate and instruction issue together: 65 line requests of 128 B per read behind the L2 (x2.0 of the algorithmic bytes = 0.74 of the HBM peak, part of it served by the Infinity Cache) and about 680 VALU + 485 scalar wave-instructions per read at EIGHT waves per SIMD (end of round 3: sequential-groups form, 64 VGPRs; locality order on all 32 bits of the minimiser hash, every look-up through the uniform table) (DESIGN.md 5.2)",
                          # a probe pass is up to three launches of the kernel: a sample of 1/128 of the range, the rest (the instantiation the sample picked), and the
                          # few reads the first two listed; kernel_ms and the bytes are those of the whole pass (sum over its launches)
                          "valu": valu,
@@ -431,10 +431,10 @@ def main():
             return {"device_ms": s4.device_ms, "wall_ms_first_call": 1e3 * w41, "wall_ms": 1e3 * w4, "nodes_contracted": s4.nodes_contracted, "removed": s4.removed, "loop_iterations": s4.loop_iterations,
                     "edges_left": s4.edges, "reads_on_edges": s4.reads_on_edges}
         if world == 1 and not sharded and not args.no_scaling_model:
-            # what a rank of a multi-GPU run would do differently: no minimiser groups once share x (N - 8 M) / 10.5 M < 1 (the library's rule) -- measured here (one untimed
+            # what a rank of a multi-GPU run would do differently: no minimiser groups below 100 M reads per rank (the library's rule) -- measured here (one untimed
             # build + probe pass with the groups switched off), then the model
             alt = None
-            if st.unique_reads - 8e6 >= 10.5e6 and args.err_ppm == 0:
+            if st.unique_reads >= 100e6 and args.err_ppm == 0:
                 saved = os.environ.get("SAGE2OV_MINIMIZER_INDEX")
                 os.environ["SAGE2OV_MINIMIZER_INDEX"] = "0"
                 try:

@@ -422,13 +422,13 @@ int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t
     WS(slots_ws, u64, WS_SLOTS, d->T); d->slots = slots_ws;
     WS(big, u64, WS_BIG, (u64)big_cap * 3);
     WS(csr_ws, u32, WS_CSR, std::max<u64>(1, 4 * N)); d->csr = csr_ws;
-    // The minimiser groups (second access path of the fast kernel) serve the reads that START a run of the locality order -- a quarter of the reads
-    // since window reuse -- and pay when the uniform table is far beyond the caches.  Measured at the end of round 3 (tests/diag/groups_by_size.py; probe time
-    // saved at full share / build time, ms): N = 10.2 M 0.5 / 1.5, 13.6 M 1.5 / 2.0, 17 M 2.0 / 2.5, 20.4 M 3.2 / 2.9, 25.5 M 5.9 / 3.8, 42.5 M 19.9 / 5.9 -- the
-    // ratio grows like (N - 8 M) / 10.5 M, and the saving scales with the share of the reads this context probes while the build does not.  So they are
-    // built when share x (N - 8 M) / 10.5 M >= 1: from 18.5 M reads on one GPU, for configs[2] on two ranks but not on four;
-    // SAGE2OV_MINIMIZER_INDEX=0/1 overrides (tests force 1 on small inputs).
-    bool wantMI = d->probeShare * ((double)N - 8e6) >= 10.5e6 && !d->diet;
+    // The minimiser groups (second access path of the fast kernel) serve the reads that START a run of the locality order, and pay when the uniform table is
+    // far beyond the caches.  With the locality order on all 32 bits of the minimiser hash (end of round 3) fewer reads start a run, and the groups no longer pay
+    // at BASELINE configs[2] (tests/diag/groups_by_size.py; probe time saved at full share / build time, ms): N = 10.2 M -0.1 / 1.5, 17 M 0.5 / 2.4, 20.4 M 0.9 / 2.9,
+    // 25.5 M 1.8 / 3.8, 42.5 M 4.2 / 6.1, 68 M 8.5 / 10.0 -- the ratio creeps towards 1 at about 100 M reads, and the saving scales with the share of the reads this
+    // context probes while the build does not.  So they are built when N x share >= 100 M (the order on 27 bits had them pay from 18.5 M reads on: 19.9 / 5.9 at
+    // configs[2]); SAGE2OV_MINIMIZER_INDEX=0/1 overrides (tests force 1 on small inputs).
+    bool wantMI = d->probeShare * (double)N >= 100e6 && !d->diet;
     if (const char* ev = getenv("SAGE2OV_MINIMIZER_INDEX")) wantMI = atoi(ev) != 0;
     if (getenv("SAGE2OV_NO_MINIMIZER_INDEX") || (d->h - std::min(d->h, 16) + 1) < 8) wantMI = false;
     u64 TL = 0; int tlBits = 0; u64 gW = 0;
