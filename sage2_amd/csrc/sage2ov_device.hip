@@ -600,6 +600,7 @@ static ProbeArgs base_args(Device* d) {
     A.reads = d->readsLoc; A.idOf = d->idOf; A.statusP = d->statusP; A.meta = getenv("SAGE2OV_NO_WINDOW_REUSE") ? nullptr : d->metaP; A.N = d->N; A.S = d->S; A.k = d->k; A.h = d->h; A.slots = d->slots; A.T = d->T; A.csr = d->csr; A.seed = d->seed;
     A.right = d->right; A.left = d->left; A.conn = d->conn; A.cflag = d->cflag; A.status = d->status; A.counters = d->d_counters;
     A.mi1 = d->mi1; A.TL = d->TL; A.krec = d->krec; A.uniL = d->uniL;
+    A.chunkShift = (u32)FAST_CHUNK_LOG;      // (plan_fast_grid may double the positions per block visit)
     return A;
 }
 
@@ -652,7 +653,12 @@ static unsigned plan_fast_grid(ProbeArgs& A, u64 n, bool writesHits = false) {
     const char* eu = getenv("SAGE2OV_FAST_BLOCKS_PER_CU"); const int uniform = eu ? std::max(1, atoi(eu)) : 0;
     const char* ep = getenv("SAGE2OV_TEST_PHASE_BLOCKS"); const u64 PB = ep ? (u64)std::max(1, atoi(ep)) : 4096;
     memset(A.phase, 0, sizeof A.phase);
-    const u64 C = (n + FAST_CHUNK - 1) / FAST_CHUNK;
+    // positions per block visit: twice FAST_CHUNK for launches big enough that the coarser grid does not show (kernels_probe_fast.inc: 24 M positions and more;
+    // SAGE2OV_FAST_CHUNK_SHIFT = 7 / 8 overrides); launches that write hits out keep the small size
+    u32 cs = (u32)FAST_CHUNK_LOG + ((n >= 24000000ull && !writesHits) ? 1u : 0u);
+    if (const char* ec = getenv("SAGE2OV_FAST_CHUNK_SHIFT")) cs = (u32)std::max(FAST_CHUNK_LOG, std::min(FAST_CHUNK_LOG + 1, atoi(ec)));
+    A.chunkShift = cs;
+    const u64 CH = 1ull << cs, C = (n + CH - 1) / CH;
     if (writesHits || uniform || C <= PB * 8) {
         const char* eh = getenv("SAGE2OV_FAST_HITS_BLOCKS_PER_CU"); const int hitsPerCu = eh ? std::max(1, atoi(eh)) : 16;
         const u64 nb = std::max<u64>(1, std::min<u64>(C, 256ull * (writesHits ? hitsPerCu : (uniform ? uniform : 16))));
@@ -702,7 +708,7 @@ int dev_probe(Device* d, uint64_t lo, uint64_t hi, std::string& err) {
         const u64 sampleMin = evs ? strtoull(evs, nullptr, 10) : (128u << 10);
         const char* evt = getenv("SAGE2OV_PROBE_TAIL");                       // "0" / "1" / "2": no sampling, that kernel for everything
         u64 nsample = (nreads >= 4 * sampleMin && !evt) ? std::max<u64>(nreads / 128, sampleMin) : 0;   // (on noisy data the sample is work done twice)
-        nsample = (nsample + FAST_CHUNK - 1) / FAST_CHUNK * FAST_CHUNK;
+        nsample = (nsample + 2 * FAST_CHUNK - 1) / (2 * FAST_CHUNK) * (2 * FAST_CHUNK);
         int tailKernel = evt ? atoi(evt) : 1; bool anyListed = evt && tailKernel == 0;       // 0 / 1 / 2: see k_probe_fast
         bool launched = true, mainWide = false;
         u64 nslow = 0, ncap = 0; float kms = 0;

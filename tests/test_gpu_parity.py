@@ -873,16 +873,19 @@ def test_probe_kernel_choice_is_exact(pd, k, mode, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("chunk_shift", ["7", "8"])
 @pytest.mark.parametrize("phase_blocks", ["1", "3", "7"])
 @pytest.mark.parametrize("pd,k", [
     (dict(seed=81, genome_len=60000, n_reads=20000, read_len=150, err_ppm=0), 40),
     (dict(seed=82, genome_len=45000, n_reads=15000, read_len=150, read_len_min=100, err_ppm=700), 33),
 ])
-def test_tapered_grid_of_the_fast_kernel_is_exact(pd, k, phase_blocks, monkeypatch):
+def test_tapered_grid_of_the_fast_kernel_is_exact(pd, k, phase_blocks, chunk_shift, monkeypatch):
     """Big launches of the fast probe kernel run a TAPERED grid (plan_fast_grid: up to three phases of 4096 blocks that take 3/4 of the remaining chunks each, then short
     blocks -- the launch has no long tail); SAGE2OV_TEST_PHASE_BLOCKS shrinks a phase to a few blocks so that a few thousand reads walk through all four phases.
-    Every chunk must be visited exactly once: the oracle's records, counters and edges."""
+    Every chunk must be visited exactly once: the oracle's records, counters and edges.  A block takes 128 positions per visit, 256 in launches over 24 M positions
+    and more (ProbeArgs::chunkShift; SAGE2OV_FAST_CHUNK_SHIFT forces either size here)."""
     monkeypatch.setenv("SAGE2OV_TEST_PHASE_BLOCKS", phase_blocks)
+    monkeypatch.setenv("SAGE2OV_FAST_CHUNK_SHIFT", chunk_shift)
     monkeypatch.setenv("SAGE2OV_PROBE_TAIL", "1")                                   # (one launch over the whole range with the kernel that settles inconsistent reads itself)
     bases, off = fx.make_reads(pd)
     m = dict(k=k)
