@@ -422,13 +422,12 @@ int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t
     WS(slots_ws, u64, WS_SLOTS, d->T); d->slots = slots_ws;
     WS(big, u64, WS_BIG, (u64)big_cap * 3);
     WS(csr_ws, u32, WS_CSR, std::max<u64>(1, 4 * N)); d->csr = csr_ws;
-    // The minimiser groups (second access path of the fast kernel) serve the reads that START a run of the locality order, and pay when the uniform table is
-    // far beyond the caches.  With the locality order on all 32 bits of the minimiser hash (end of round 3) fewer reads start a run, and the groups no longer pay
-    // at BASELINE configs[2] (tests/diag/groups_by_size.py; probe time saved at full share / build time, ms): N = 10.2 M -0.1 / 1.5, 17 M 0.5 / 2.4, 20.4 M 0.9 / 2.9,
-    // 25.5 M 1.8 / 3.8, 42.5 M 4.2 / 6.1, 68 M 8.5 / 10.0 -- the ratio creeps towards 1 at about 100 M reads, and the saving scales with the share of the reads this
-    // context probes while the build does not.  So they are built when N x share >= 100 M (the order on 27 bits had them pay from 18.5 M reads on: 19.9 / 5.9 at
-    // configs[2]); SAGE2OV_MINIMIZER_INDEX=0/1 overrides (tests force 1 on small inputs).
-    bool wantMI = d->probeShare * (double)N >= 100e6 && !d->diet;
+    // The minimiser groups (second access path of the fast kernel) serve the reads that START a run of the locality order.  With the locality order on all 32 bits
+    // of the minimiser hash (end of round 3) few reads start a run, and the groups cost more to build than they save at every size measured
+    // (tests/diag/groups_by_size.py; probe time saved at full share / build time, ms): N = 10.2 M -0.1 / 1.5, 17 M 0.5 / 2.4, 25.5 M 1.8 / 3.8, 42.5 M 4.2 / 6.1,
+    // 68 M 8.5 / 10.0, 102 M 12.1 / 16.2 -- the ratio levels off near 0.8 (with the order on 27 bits they paid from 18.5 M reads on: 19.9 / 5.9 at configs[2]).
+    // So they are built on request only: SAGE2OV_MINIMIZER_INDEX=1 (the test suite does, on its small inputs; the code path stays exact and covered).
+    bool wantMI = false;
     if (const char* ev = getenv("SAGE2OV_MINIMIZER_INDEX")) wantMI = atoi(ev) != 0;
     if (getenv("SAGE2OV_NO_MINIMIZER_INDEX") || (d->h - std::min(d->h, 16) + 1) < 8) wantMI = false;
     u64 TL = 0; int tlBits = 0; u64 gW = 0;
