@@ -50,7 +50,7 @@ XGMI_LINK_GBS = 153.0          # MI355X_MICROARCH.md / task notes: 7 xGMI links 
 
 def scaling_model(n_unique, n_edges, ms1, ph, alt=None):
     """MODEL, UNMEASURED: the step time on G ranks predicted from the ONE-GPU phase times of this run (no multi-GPU hardware is available to the
-    builder; the driver's scaling runs are the measurement).  Per rank: replicated = index build (no minimiser groups: the library builds them on request only, dev_build_index) + cond half of the reciprocal pass + hit lists / adjacency of the reduce phase + convert; sharded = probe pass,
+    builder; the driver's scaling runs are the measurement).  Per rank: replicated = index build (no minimiser groups: the library decides by the share of reads without a predecessor, 9.5 % at this coverage: dev_build_index) + cond half of the reciprocal pass + hit lists / adjacency of the reduce phase + convert; sharded = probe pass,
     emit half of the reciprocal pass, marks of the reduce phase; exchanges = records (16 B/read), containment planes (2 B/read, all-reduce), edge
     and survivor buckets (16 B/edge), each rank receiving (G-1)/G of the bytes over G-1 links at `link_efficiency` of one direction of a link,
     plus a fixed latency per collective.  ph: phases of the one-GPU step (ms); alt: index / probe times measured without minimiser groups."""
@@ -430,8 +430,7 @@ def main():
             return {"device_ms": s4.device_ms, "wall_ms_first_call": 1e3 * w41, "wall_ms": 1e3 * w4, "nodes_contracted": s4.nodes_contracted, "removed": s4.removed, "loop_iterations": s4.loop_iterations,
                     "edges_left": s4.edges, "reads_on_edges": s4.reads_on_edges}
         if world == 1 and not sharded and not args.no_scaling_model:
-            # what a rank of a multi-GPU run would do differently: nothing by default; if this run forces the minimiser groups on (SAGE2OV_MINIMIZER_INDEX=1: the library
-            # builds them on request only), the pass without them is measured here (one untimed build + probe pass with the groups switched off), then the model
+            # what a rank of a multi-GPU run would do differently: nothing at this coverage; if this run forces the minimiser groups on (SAGE2OV_MINIMIZER_INDEX=1), the pass without them is measured here (one untimed build + probe pass with the groups switched off), then the model
             alt = None
             if os.environ.get("SAGE2OV_MINIMIZER_INDEX") == "1" and args.err_ppm == 0:
                 saved = os.environ.get("SAGE2OV_MINIMIZER_INDEX")

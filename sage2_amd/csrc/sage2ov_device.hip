@@ -47,6 +47,7 @@ struct Device {
     hipEvent_t ev[8] = {};
     // reads
     u64 N = 0; int S = 0, maxL = 0, k = 0, h = 0; double probeShare = 1.0;
+    u64* d_runStarts = nullptr; u64* h_runStarts = nullptr; hipEvent_t evRunStarts = nullptr; bool runStartsValid = false; double runStartFrac = 0.0;      // share of the reads without a predecessor in the locality order (counted by k_loc_index into d_runStarts)
     u64* reads = nullptr;        // (N+1)*S words, slot i = read id i
     // the same reads in LOCALITY order (slot p = the read at position p of the order by global minimiser): what the index entries point at and
     // what the probe kernels gather from -- a read's overlap partners are neighbours in the genome, hence (mostly) neighbours here
@@ -151,8 +152,11 @@ Device* dev_create(int ordinal, std::string& err) {
       const u32 fmask = (nf >= 0 && nf < 20) ? ((1u << nf) - 1u) : 0xFFFFFu;
       if (hipMemcpyToSymbol(HIP_SYMBOL(g_fp_mask), &fmask, sizeof fmask) != hipSuccess) { err = "fingerprint mask upload failed"; delete d; return nullptr; } }
     for (auto& ev : d->ev) hipEventCreate(&ev);
-    if (hipMalloc(&d->d_counters, 24 * sizeof(u64)) != hipSuccess) { err = "hipMalloc(counters) failed"; delete d; return nullptr; }
-    hipMemset(d->d_counters, 0, 24 * sizeof(u64));
+    if (hipMalloc(&d->d_counters, (24 + 64) * sizeof(u64)) != hipSuccess) { err = "hipMalloc(counters) failed"; delete d; return nullptr; }
+    hipMemset(d->d_counters, 0, (24 + 64) * sizeof(u64));
+    d->d_runStarts = d->d_counters + 24;
+    if (hipHostMalloc((void**)&d->h_runStarts, 64 * sizeof(u64), hipHostMallocDefault) != hipSuccess || hipEventCreateWithFlags(&d->evRunStarts, hipEventDisableTiming) != hipSuccess) {
+        err = "hipHostMalloc / hipEventCreate failed"; hipFree(d->d_counters); delete d; return nullptr; }
     return d;
 }
 static void rr_staging_release(Device* d);
@@ -170,7 +174,7 @@ void dev_destroy(Device* d) {
     hipSetDevice(d->ordinal);
     hipStreamSynchronize(d->stream);
     dev_simplify_release(d); rr_staging_release(d);
-    free_reads(d); hipFree(d->d_counters);
+    free_reads(d); hipFree(d->d_counters); if (d->h_runStarts) hipHostFree(d->h_runStarts); if (d->evRunStarts) hipEventDestroy(d->evRunStarts);
     for (auto& ev : d->ev) if (ev) hipEventDestroy(ev);
     hipStreamDestroy(d->stream);
     delete d;
@@ -320,9 +324,16 @@ static int build_locality_order(Device* d, u64 lo, u64 hi, const u32** order_out
 // Round 3: two kernels.  k_loc_index writes the translation tables from the order; k_loc_scatter then STREAMS the id-ordered store (coalesced reads) and
 // writes every slot to its position (whole 32 / 64 / 128-byte slots: no read-modify-write at the memory side).  The gather it replaces pulled every
 // 64-byte slot as a 128-byte line request: 5.4 GB of reads for 2.7 GB of reads at configs[2].
-__global__ void k_loc_index(const u32* __restrict__ order, u64 N, u32* idOf, u32* posOf, unsigned short* meta) {      // order: 3 dwords per position {hash, id, meta}
+// runStarts (64 words, zeroed by the host; their sum, over every eighth block): positions whose read has another minimiser or another strand of it than the read before -- reads that cannot take their windows
+// over from a predecessor (kernels_probe_fast.inc); their share decides whether the minimiser groups are built (dev_build_index)
+__global__ void k_loc_index(const u32* __restrict__ order, u64 N, u32* idOf, u32* posOf, unsigned short* meta, unsigned long long* runStarts) {      // order: 3 dwords per position {hash, id, meta}
     const u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (p == 0) { idOf[0] = 0; posOf[0] = 0; idOf[N + 1] = 0; posOf[N + 1] = 0; meta[0] = 0xFFFF; meta[N + 1] = 0xFFFF; }
+    if ((blockIdx.x & 7u) == 0) {                                         // (every eighth block of 256 positions: a sample is all the decision needs; one atomic per sampled block)
+        const bool start = order && p < N && (p == 0 || order[3 * p] != order[3 * (p - 1)] || ((order[3 * p + 2] ^ order[3 * (p - 1) + 2]) & 0x100u) != 0);
+        const int c = __syncthreads_count(start);
+        if (threadIdx.x == 0 && c) atomicAdd(runStarts + ((blockIdx.x >> 3) & 63u), (unsigned long long)c);
+    }
     if (p >= N) return;
     const u32 id = order ? order[3 * p + 1] : (u32)(p + 1); const u32 mt = order ? order[3 * p + 2] : 0xFFFFu;
     idOf[p + 1] = id; posOf[id] = (u32)(p + 1); meta[p + 1] = (unsigned short)mt;       // meta 0xFFFF: no minimiser information (no window reuse)
@@ -346,7 +357,11 @@ static int build_locality_store(Device* d, std::string& err) {
     d->readsLoc = rl; d->idOf = io; d->posOf = po; d->statusP = sp; d->metaP = me;
     const u32* order = nullptr;
     if (N && !getenv("SAGE2OV_NO_LOCALITY")) { int rc = build_locality_order(d, 1, N + 1, &order, err); if (rc) return rc; }
-    hipLaunchKernelGGL(k_loc_index, dim3(grid_for(std::max<u64>(N, 1), 256)), dim3(256), 0, d->stream, order, (u64)N, io, po, me);
+    HIPCHK(hipMemsetAsync(d->d_runStarts, 0, 64 * sizeof(u64), d->stream));                   // run starts of the order (k_loc_index)
+    hipLaunchKernelGGL(k_loc_index, dim3(grid_for(std::max<u64>(N, 1), 256)), dim3(256), 0, d->stream, order, (u64)N, io, po, me, (unsigned long long*)d->d_runStarts);
+    d->runStartsValid = order != nullptr;
+    // (the count travels to a pinned word while k_loc_scatter below runs: dev_build_index waits for the copy's event, not for the stream)
+    if (d->runStartsValid) { HIPCHK(hipMemcpyAsync(d->h_runStarts, d->d_runStarts, 64 * sizeof(u64), hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipEventRecord(d->evRunStarts, d->stream)); }
     if (d->diet) { HIPCHK(hipStreamSynchronize(d->stream)); ws_free(d, WS_MINH); ws_free(d, WS_OCUR); }       // the order's sort buffers (24 bytes per read) go before the tuples come
     hipLaunchKernelGGL(k_loc_scatter, dim3(grid_for((N + 1) * (d->S / 2), 256)), dim3(256), 0, d->stream, d->reads, po, (u64)N, d->S, rl);
     HIPCHK(hipGetLastError());
@@ -397,6 +412,8 @@ static void pt_first_digit(u64 nWin, int shiftW, int* shift0, u32* mask0, int* d
     const int bper = (wb + nd - 1) / nd; *shift0 = shiftW; *mask0 = (1u << std::min(bper, wb)) - 1u; *doHist = 1;
 }
 
+// (probe time the minimiser groups save) / (what they cost to build) at full share, as a function of the share f of reads without a predecessor: see dev_build_index
+static inline double RUN_START_RULE(double f) { return f > 0.1 ? 27.0 * (f - 0.1) : 0.0; }
 int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t* csr_out, uint64_t* nlong_out, uint32_t* rebuilds, std::string& err) {
     HIPCHK(hipSetDevice(d->ordinal));
     const u64 N = d->N; if (!d->reads && !d->readsLoc) { err = "reads not resident"; return SAGE2OV_ERR_ARG; }
@@ -422,12 +439,22 @@ int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t
     WS(slots_ws, u64, WS_SLOTS, d->T); d->slots = slots_ws;
     WS(big, u64, WS_BIG, (u64)big_cap * 3);
     WS(csr_ws, u32, WS_CSR, std::max<u64>(1, 4 * N)); d->csr = csr_ws;
-    // The minimiser groups (second access path of the fast kernel) serve the reads that START a run of the locality order.  With the locality order on all 32 bits
-    // of the minimiser hash (end of round 3) few reads start a run, and the groups cost more to build than they save at every size measured
-    // (tests/diag/groups_by_size.py; probe time saved at full share / build time, ms): N = 10.2 M -0.1 / 1.5, 17 M 0.5 / 2.4, 25.5 M 1.8 / 3.8, 42.5 M 4.2 / 6.1,
-    // 68 M 8.5 / 10.0, 102 M 12.1 / 16.2 -- the ratio levels off near 0.8 (with the order on 27 bits they paid from 18.5 M reads on: 19.9 / 5.9 at configs[2]).
-    // So they are built on request only: SAGE2OV_MINIMIZER_INDEX=1 (the test suite does, on its small inputs; the code path stays exact and covered).
-    bool wantMI = false;
+    // The minimiser groups (second access path of the fast kernel) serve the reads that START a run of the locality order -- reads with another minimiser, or another
+    // strand of it, than the read before: every one of their windows is a random line of the uniform table otherwise.  How many there are is a property of the data
+    // (coverage: a minimiser's reads are a run per strand), counted by k_loc_index.  Measured at the end of round 3 with the order on all 32 hash bits
+    // (tests/diag/groups_by_coverage.py, groups_by_size.py; share of such reads -> probe time saved at full share / build time, ms): 34-39 M reads at 10x / 20x / 30x / 50x
+    // coverage 30.5 % -> 35.3 / 6.2, 18.8 % -> 13.0 / 5.8, 13.9 % -> 6.6 / 5.5, 9.4 % -> 2.0 / 5.2; 8.5-9.7 M reads 32.2 % -> 6.8 / 1.7, 19.4 % -> 2.2 / 1.5, 14.2 % -> 0.9 / 1.4,
+    // 9.5 % -> -0.1 / 1.3; 50x (9.5 %) at 42.5 M, 68 M and 102 M reads 4.2 / 6.1, 8.5 / 10.0 and 12.1 / 16.2.  The ratio is close to 27 (f - 0.1) from 20 M reads on and 0.72
+    // of that below (RUN_START_RULE); the saving scales with the share of the reads this context probes, the build does not: built iff share x ratio >= 1.
+    if (d->runStartsValid) {
+        HIPCHK(hipEventSynchronize(d->evRunStarts));
+        u64 rs = 0; for (int x = 0; x < 64; x++) rs += d->h_runStarts[x];
+        u64 sampled = 0; for (u64 b0 = 0; b0 * 256 < N; b0 += 8) sampled += std::min<u64>(256, N - b0 * 256);      // positions of the sampled blocks
+        d->runStartFrac = sampled ? (double)rs / (double)sampled : 0.0; d->runStartsValid = false;      // (kept: a diet-mode rebuild reuses the order)
+    }
+    const double f_ = d->runStartFrac, sizeFactor = N >= 20000000ull ? 1.0 : 0.72;
+    bool wantMI = !d->diet && N >= 2000000ull && d->probeShare * sizeFactor * RUN_START_RULE(f_) >= 1.0;
+    if (getenv("SAGE2OV_TIMING")) fprintf(stderr, "[index] reads without a predecessor in the locality order: %.1f %% -> minimiser groups %s\n", 100.0 * f_, wantMI ? "built" : "not built");
     if (const char* ev = getenv("SAGE2OV_MINIMIZER_INDEX")) wantMI = atoi(ev) != 0;
     if (getenv("SAGE2OV_NO_MINIMIZER_INDEX") || (d->h - std::min(d->h, 16) + 1) < 8) wantMI = false;
     u64 TL = 0; int tlBits = 0; u64 gW = 0;
