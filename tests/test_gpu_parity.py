@@ -873,6 +873,24 @@ def test_probe_kernel_choice_is_exact(pd, k, mode, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_minimiser_groups_by_the_run_start_rule_change_nothing_but_time(monkeypatch):
+    """dev_build_index builds the minimiser groups when enough reads have another minimiser (or strand of it) than the read before them in the locality order -- low
+    coverage: 2.3 M reads at 8x here, above the rule's 2 M-read floor -- and not otherwise.  Built by the rule, forced off and forced on: the same edge list and counters."""
+    import zlib
+    p = fx.synth_params(dict(seed=17, genome_len=45_000_000, n_reads=2_400_000, read_len=150))
+    genome = s2.synth_genome(p); res = []
+    for mode in (None, "0", "1"):
+        if mode is None:
+            monkeypatch.delenv("SAGE2OV_MINIMIZER_INDEX", raising=False)
+        else:
+            monkeypatch.setenv("SAGE2OV_MINIMIZER_INDEX", mode)
+        c = s2.Context(40, device=0); c.reads_add_synth(p, genome); c.reads_organize(); c.run_steps23()
+        e = c.edges(); st = c.overlap_stats()
+        res.append((zlib.crc32(e.tobytes()), len(e), st.verified_overlaps, st.contained_extension, st.edges)); c.close()
+    assert res[0] == res[1] == res[2] and res[0][1] > 1_000_000
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("chunk_shift", ["7", "8"])
 @pytest.mark.parametrize("phase_blocks", ["1", "3", "7"])
 @pytest.mark.parametrize("pd,k", [
