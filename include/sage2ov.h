@@ -106,6 +106,9 @@ typedef struct sage2ov_index_stats {
     uint64_t long_buckets;   /* buckets with >= 100 entries (hashTable.cpp:111-123): never found */
     uint32_t hash_string_length;
     uint32_t rebuilds;       /* reseeds after an impure long bucket */
+    uint32_t minimiser_groups; /* 1: the fast probe kernel's second access path (keys grouped by minimiser) was built and is used; the library decides
+                                * by the share of reads without a predecessor in the locality order */
+    uint32_t reserved;
 } sage2ov_index_stats;
 int sage2ov_index_build(sage2ov_ctx* ctx);                      /* hashPrefixesAndSuffix (hashTable.cpp:70) */
 int sage2ov_index_stats_get(const sage2ov_ctx* ctx, sage2ov_index_stats* out);

@@ -31,7 +31,7 @@ class ReadStats(C.Structure):
 
 class IndexStats(C.Structure):
     _fields_ = [("slots", C.c_uint64), ("keys", C.c_uint64), ("csr_entries", C.c_uint64), ("long_buckets", C.c_uint64),
-                ("hash_string_length", C.c_uint32), ("rebuilds", C.c_uint32)]
+                ("hash_string_length", C.c_uint32), ("rebuilds", C.c_uint32), ("minimiser_groups", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class OverlapStats(C.Structure):

@@ -35,13 +35,14 @@ static double now() { return chrono::duration<double>(chrono::steady_clock::now(
 
 int main(int argc, char* argv[]) {
     const double tMain = now(); const bool timing = getenv("SAGE2OV_TIMING") != nullptr;
-    int minStep = 1, maxStep = 3, gpu = 0, gpus = 1; bool shareGpu = false, forceMulti = false; unsigned minOverlap = 0; bool saveAll = false, debugging = false, fFlag = false, lFlag = false;
+    int minStep = 1, maxStep = 3, gpu = 0, gpus = 1, failRank = -1; bool shareGpu = false, forceMulti = false; unsigned minOverlap = 0; bool saveAll = false, debugging = false, fFlag = false, lFlag = false;
     string fileInput, listInput, outputDir, prefixName = "untitled", inputPrefix;
     static struct option opts[] = {{"help", no_argument, 0, 'h'}, {"fileInput", required_argument, 0, 'f'}, {"minOverlap", required_argument, 0, 'k'},
         {"listInput", required_argument, 0, 'l'}, {"outputDir", required_argument, 0, 'o'}, {"prefix", required_argument, 0, 'p'},
         {"inputPrefix", required_argument, 0, 'i'}, {"minStep", required_argument, 0, 'm'}, {"maxStep", required_argument, 0, 'M'},
         {"saveAll", no_argument, 0, 's'}, {"debug", no_argument, 0, 'd'}, {"gpu", required_argument, 0, 'g'}, {"gpus", required_argument, 0, 'G'},
         {"share-gpu", no_argument, 0, 1001},      // rehearsal: all ranks on device `gpu`, exchanges by device copies instead of RCCL (a box with fewer GPUs than ranks)
+        {"fail-rank", required_argument, 0, 1003},  // tests: this rank of a multi-GPU run fails before its first step (the run must end non-zero, not hang)
         {"force-multi", no_argument, 0, 1002},    // the multi-GPU code path (RCCL communicator, the four exchanges) even with one GPU
         {0, 0, 0, 0}};
     int c, oi = 0;
@@ -62,6 +63,7 @@ int main(int argc, char* argv[]) {
             case 'G': gpus = atoi(optarg); if (gpus < 1) gpus = 1; break;
             case 1001: shareGpu = true; break;
             case 1002: forceMulti = true; break;
+            case 1003: failRank = atoi(optarg); break;
             case '?': cout << "\n"; exit(0);
             default: cout << "[ERROR] Wrong command line arguments!\n\n"; exit(0);
         }
@@ -130,7 +132,7 @@ int main(int argc, char* argv[]) {
                     all.push_back(others.back()->get()); devs.push_back(dev);
                 }
             }
-            string merr; int mrc = sage2ov_multi::run_steps23(all, devs, shareGpu, merr);
+            string merr; int mrc = sage2ov_multi::run_steps23(all, devs, shareGpu, merr, failRank);
             if (mrc) throw Error(mrc, merr);
             sage2ov_index_stats is{}; ctx.check(sage2ov_index_stats_get(ctx.get(), &is)); sage2ov_overlap_stats os{}; ctx.check(sage2ov_overlap_stats_get(ctx.get(), &os));
             logStream << "STEPS 2-3 on " << gpus << (shareGpu ? " ranks sharing GPU " : " GPUs starting at ") << gpu << (shareGpu ? " (rehearsal transport)" : " (RCCL)") << "\n\t         Hash string length: " << is.hash_string_length

@@ -166,6 +166,7 @@ static void free_reads(Device* d) {
     hipFree(d->status); hipFree(d->cand);     // slots / csr / final_edges live in the workspace arena
     for (auto& b : d->ws) { if (b.p) hipFree(b.p); b.p = nullptr; b.cap = 0; }
     s4cache_release(d);
+    d->runStartFrac = 0.0; d->runStartsValid = false;          // (measured on the read set that just went: a new one decides for itself)
     d->readsLoc = nullptr; d->idOf = d->posOf = nullptr; d->statusP = nullptr; d->metaP = nullptr; d->mi1 = d->krec = nullptr; d->cand_cap = 0; d->n_cand = 0;
     d->reads = d->slots = nullptr; d->csr = nullptr; d->right = d->left = nullptr; d->conn = d->cflag = nullptr; d->status = nullptr; d->cand = nullptr; d->final_edges = nullptr;
 }
@@ -339,12 +340,14 @@ __global__ void k_loc_index(const u32* __restrict__ order, u64 N, u32* idOf, u32
     idOf[p + 1] = id; posOf[id] = (u32)(p + 1); meta[p + 1] = (unsigned short)mt;       // meta 0xFFFF: no minimiser information (no window reuse)
 }
 __global__ void k_loc_scatter(const u64* __restrict__ reads, const u32* __restrict__ posOf, u64 N, int S, u64* out) {
-    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;      // one 16-byte piece of a slot per thread
-    const int H = S / 2;
-    if (t >= (N + 1) * H) return;
-    const u64 id = t / H; const int c = (int)(t % H);
-    const ulonglong2 v = ((const ulonglong2*)reads)[t];            // (slot 0 is all zero and stays at position 0: posOf[0] = 0)
-    ((ulonglong2*)out)[(u64)posOf[id] * H + c] = v;
+    // one 16-byte piece of a slot per thread and step; grid-stride: (N + 1) * S / 2 pieces reach 2^32 from 2^29 reads of the 16-word layout on, and a launch
+    // of 2^32 threads or more runs modulo 2^32 (grid_for_capped)
+    const int H = S / 2; const u64 total = (N + 1) * H, stride = (u64)gridDim.x * blockDim.x;
+    for (u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+        const u64 id = t / H; const int c = (int)(t % H);
+        const ulonglong2 v = ((const ulonglong2*)reads)[t];        // (slot 0 is all zero and stays at position 0: posOf[0] = 0)
+        ((ulonglong2*)out)[(u64)posOf[id] * H + c] = v;
+    }
 }
 __global__ void k_status_by_pos(const u32* __restrict__ idOf, const uint8_t* __restrict__ status, u64 N, uint8_t* statusP) {
     const u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x; if (p > N) return; statusP[p] = p ? status[idOf[p]] : (uint8_t)0xFF;
@@ -360,10 +363,11 @@ static int build_locality_store(Device* d, std::string& err) {
     HIPCHK(hipMemsetAsync(d->d_runStarts, 0, 64 * sizeof(u64), d->stream));                   // run starts of the order (k_loc_index)
     hipLaunchKernelGGL(k_loc_index, dim3(grid_for(std::max<u64>(N, 1), 256)), dim3(256), 0, d->stream, order, (u64)N, io, po, me, (unsigned long long*)d->d_runStarts);
     d->runStartsValid = order != nullptr;
+    if (!order) d->runStartFrac = 0.0;
     // (the count travels to a pinned word while k_loc_scatter below runs: dev_build_index waits for the copy's event, not for the stream)
     if (d->runStartsValid) { HIPCHK(hipMemcpyAsync(d->h_runStarts, d->d_runStarts, 64 * sizeof(u64), hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipEventRecord(d->evRunStarts, d->stream)); }
     if (d->diet) { HIPCHK(hipStreamSynchronize(d->stream)); ws_free(d, WS_MINH); ws_free(d, WS_OCUR); }       // the order's sort buffers (24 bytes per read) go before the tuples come
-    hipLaunchKernelGGL(k_loc_scatter, dim3(grid_for((N + 1) * (d->S / 2), 256)), dim3(256), 0, d->stream, d->reads, po, (u64)N, d->S, rl);
+    hipLaunchKernelGGL(k_loc_scatter, dim3(grid_for_capped((N + 1) * (d->S / 2), 256)), dim3(256), 0, d->stream, d->reads, po, (u64)N, d->S, rl);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -703,6 +707,7 @@ static unsigned plan_fast_grid(ProbeArgs& A, u64 n, bool writesHits = false) {
 }
 
 void dev_set_probe_share(Device* d, double share) { d->probeShare = share; }
+bool dev_has_minimiser_groups(Device* d) { return d->mi1 != nullptr && d->TL != 0; }
 
 int dev_probe(Device* d, uint64_t lo, uint64_t hi, std::string& err) {
     HIPCHK(hipSetDevice(d->ordinal));

@@ -927,7 +927,7 @@ int sage2ov_index_build(sage2ov_ctx* c) {
     uint64_t slots, keys, csr, nlong; uint32_t reb;
     int rc = dev_build_index(c->device(), &slots, &keys, &csr, &nlong, &reb, c->err); if (rc) return rc;
     c->istats.slots = slots; c->istats.keys = keys; c->istats.csr_entries = csr; c->istats.long_buckets = nlong;
-    c->istats.hash_string_length = c->cfg.min_overlap > 64 ? 64 : c->cfg.min_overlap; c->istats.rebuilds = reb;
+    c->istats.hash_string_length = c->cfg.min_overlap > 64 ? 64 : c->cfg.min_overlap; c->istats.rebuilds = reb; c->istats.minimiser_groups = dev_has_minimiser_groups(c->device()) ? 1u : 0u; c->istats.reserved = 0;
     c->indexBuilt = true; c->probed = c->reciprocalDone = c->reduced = c->converted = false;
     return SAGE2OV_OK;
 }

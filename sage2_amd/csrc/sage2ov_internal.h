@@ -63,6 +63,7 @@ int dev_import_flags(Device* d, const void* dev_src, std::string& err);
 uint64_t dev_cand_count(Device* d);
 int dev_export_cands(Device* d, void* dev_dst, uint64_t cap, std::string& err);   // 16 bytes per candidate
 int dev_set_cands(Device* d, const void* dev_src, uint64_t n, std::string& err);
+bool dev_has_minimiser_groups(Device* d);
 void dev_set_probe_share(Device* d, double share);    // share of the reads this context probes (1 / world): decides whether the minimiser groups pay
 int dev_download_initial(Device* d, uint64_t* right, uint64_t* left, uint8_t* status, uint32_t* conn, std::string& err);
 // directional hit lists of status-0 reads (economyGraph.cpp:591-633), sorted by (from, seq)

@@ -13,6 +13,8 @@
 // copies between the ranks' buffers behind a thread barrier -- it exercises everything but RCCL itself, which in turn runs with one rank there.
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
+#include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstring>
@@ -30,7 +32,8 @@ struct Barrier {                                               // (C++17: no std
     std::mutex m; std::condition_variable cv; int n, waiting = 0; unsigned gen = 0; bool broken = false;
     explicit Barrier(int n_) : n(n_) {}
     bool wait() { std::unique_lock<std::mutex> l(m); if (broken) return false; const unsigned g = gen; if (++waiting == n) { waiting = 0; gen++; cv.notify_all(); } else cv.wait(l, [&] { return gen != g || broken; }); return !broken; }
-    void release_all() { std::lock_guard<std::mutex> l(m); broken = true; cv.notify_all(); }
+    void release_all() { { std::lock_guard<std::mutex> l(m); broken = true; cv.notify_all(); } failed.store(true, std::memory_order_release); }
+    std::atomic<bool> failed{false};                           // (read without the lock by ranks that poll a collective: see Rank::finish)
 };
 struct DevBuf {                                                // device memory of one rank, freed on scope exit
     void* p = nullptr; size_t cap = 0;
@@ -50,17 +53,30 @@ struct Rank {
     Shared& S; int r; sage2ov_ctx* ctx; hipStream_t st;
     Rank(Shared& s, int r_, sage2ov_ctx* c) : S(s), r(r_), ctx(c), st((hipStream_t)sage2ov_stream(c)) {}
     int fail(const char* what) { S.err[r] = what; S.bar.release_all(); return S.rc[r] = SAGE2OV_ERR_DEVICE; }
-#define BAR() do { if (!S.bar.wait()) { if (!S.rc[r]) { S.rc[r] = SAGE2OV_ERR_INTERNAL; S.err[r] = "another rank failed"; } return S.rc[r]; } } while (0)
+    int other_failed() { if (!S.rc[r]) { S.rc[r] = SAGE2OV_ERR_INTERNAL; S.err[r] = "another rank failed"; } return S.rc[r]; }
+    // The ranks are threads of one process, so a rank that fails anywhere (a library error on its GPU, a failed allocation) can tell the others: they meet at the
+    // thread barrier BEFORE every RCCL collective -- nobody enters one that a failed rank will never join -- and a rank that is already inside one polls its stream
+    // instead of blocking in hipStreamSynchronize, aborts its communicator when the flag goes up and returns (`sage2ov --gpus G` used to hang).
+    int finish() {
+        for (;;) {
+            const hipError_t q = hipStreamQuery(st);
+            if (q == hipSuccess) return 0;
+            if (q != hipErrorNotReady) return fail("stream query");
+            if (S.bar.failed.load(std::memory_order_acquire)) { if (S.comms[r]) { ncclCommAbort(S.comms[r]); S.comms[r] = nullptr; } return other_failed(); }
+            std::this_thread::sleep_for(std::chrono::microseconds(50));
+        }
+    }
+#define BAR() do { if (!S.bar.wait()) return other_failed(); } while (0)
     // every rank contributes `bytes` at send; recv gets G x bytes in rank order
     int allgather(const void* send, void* recv, size_t bytes) {
-        if (!S.shareGpu) { if (ncclAllGather(send, recv, bytes, ncclUint8, S.comms[r], st) != ncclSuccess) return fail("ncclAllGather"); return hipStreamSynchronize(st) == hipSuccess ? 0 : fail("stream sync"); }
+        if (!S.shareGpu) { BAR(); if (ncclAllGather(send, recv, bytes, ncclUint8, S.comms[r], st) != ncclSuccess) return fail("ncclAllGather"); return finish(); }
         S.sendPtr[r] = send; BAR();
         for (int q = 0; q < S.G; q++) if (bytes && hipMemcpyAsync((char*)recv + (size_t)q * bytes, S.sendPtr[q], bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail("device copy");
         if (hipStreamSynchronize(st) != hipSuccess) return fail("stream sync");       // (a device-to-device hipMemcpy may return before it has run, and nothing orders the null stream with the library's stream)
         BAR(); return 0;
     }
     int allreduce_max_bytes(void* buf, size_t bytes) {          // in place
-        if (!S.shareGpu) { if (ncclAllReduce(buf, buf, bytes, ncclUint8, ncclMax, S.comms[r], st) != ncclSuccess) return fail("ncclAllReduce"); return hipStreamSynchronize(st) == hipSuccess ? 0 : fail("stream sync"); }
+        if (!S.shareGpu) { BAR(); if (ncclAllReduce(buf, buf, bytes, ncclUint8, ncclMax, S.comms[r], st) != ncclSuccess) return fail("ncclAllReduce"); return finish(); }
         std::vector<unsigned char> mine(bytes), other(bytes);     // (rehearsal transport: through the host)
         S.sendPtr[r] = buf; BAR();
         if (hipMemcpy(mine.data(), buf, bytes, hipMemcpyDeviceToHost) != hipSuccess) return fail("copy");
@@ -75,9 +91,10 @@ struct Rank {
         if (S.shareGpu) { S.u64Slot[r] = v; BAR(); all = S.u64Slot; BAR(); return 0; }
         if (scratch.need((size_t)(S.G + 1) * 8)) return fail("hipMalloc");
         if (hipMemcpyAsync(scratch.p, &v, 8, hipMemcpyHostToDevice, st) != hipSuccess) return fail("copy");
+        BAR();
         if (ncclAllGather(scratch.p, (char*)scratch.p + 8, 8, ncclUint8, S.comms[r], st) != ncclSuccess) return fail("ncclAllGather");
         if (hipMemcpyAsync(all.data(), (char*)scratch.p + 8, (size_t)S.G * 8, hipMemcpyDeviceToHost, st) != hipSuccess) return fail("copy");
-        return hipStreamSynchronize(st) == hipSuccess ? 0 : fail("stream sync");
+        return finish();
     }
     // ragged buckets of 16-byte records: counts, then buckets padded to the largest; `out` gets the concatenation in rank order
     int allgather_buckets(const void* bucket, uint64_t n, DevBuf& padded, DevBuf& gathered, DevBuf& out, uint64_t* total, DevBuf& scratch) {
@@ -140,7 +157,7 @@ struct Rank {
 
 }  // namespace
 
-int run_steps23(const std::vector<sage2ov_ctx*>& ctx, const std::vector<int>& devices, bool share_gpu, std::string& err) {
+int run_steps23(const std::vector<sage2ov_ctx*>& ctx, const std::vector<int>& devices, bool share_gpu, std::string& err, int fail_rank) {
     const int G = (int)ctx.size();
     if (G < 1 || (int)devices.size() != G) { err = "run_steps23: one device per context"; return SAGE2OV_ERR_ARG; }
     Shared S(G, share_gpu);
@@ -148,9 +165,15 @@ int run_steps23(const std::vector<sage2ov_ctx*>& ctx, const std::vector<int>& de
         if (ncclCommInitAll(S.comms.data(), G, devices.data()) != ncclSuccess) { err = "ncclCommInitAll failed (RCCL needs one distinct GPU per rank)"; return SAGE2OV_ERR_DEVICE; }
     }
     std::vector<std::thread> th;
-    for (int r = 0; r < G; r++) th.emplace_back([&, r] { if (hipSetDevice(devices[r]) != hipSuccess) { S.rc[r] = SAGE2OV_ERR_DEVICE; S.err[r] = "hipSetDevice"; return; } Rank me(S, r, ctx[r]); me.steps23(); });
+    for (int r = 0; r < G; r++) th.emplace_back([&, r] {
+        if (hipSetDevice(devices[r]) != hipSuccess) { S.rc[r] = SAGE2OV_ERR_DEVICE; S.err[r] = "hipSetDevice"; S.bar.release_all(); return; }      // (the others must not wait for this rank)
+        Rank me(S, r, ctx[r]);
+        if (fail_rank == r) { me.fail("failure injected for this rank (test hook)"); return; }
+        me.steps23(); });
     for (auto& t : th) t.join();
     if (!share_gpu) for (auto& c : S.comms) if (c) ncclCommDestroy(c);
+    // (the rank that failed first is the one to report, not a rank that merely saw the flag)
+    for (int r = 0; r < G; r++) if (S.rc[r] && S.err[r] != "another rank failed") { err = "rank " + std::to_string(r) + ": " + S.err[r]; return S.rc[r]; }
     for (int r = 0; r < G; r++) if (S.rc[r]) { err = "rank " + std::to_string(r) + ": " + S.err[r]; return S.rc[r]; }
     return SAGE2OV_OK;
 }

@@ -12,10 +12,21 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
-@pytest.fixture(autouse=True)
-def _minimiser_groups_on_small_inputs(monkeypatch):
-    """The library builds the minimiser groups (the fast kernel's second access path) only for big read sets probed by one context
-    (dev_build_index); the tests' inputs are small, and the groups are half of the kernel's look-up code: forced on here unless the
-    environment or the test sets the switch itself (test_without_minimiser_groups_matches_oracle covers the other half)."""
+# The fast probe kernel has two access paths to the index: the uniform table and the minimiser groups.  Which one a context uses is the LIBRARY's decision
+# (dev_build_index: by the share of reads without a predecessor in the locality order -- never for the small inputs of a test, and not at BASELINE
+# configs[1] / configs[2] either).  SAGE2OV_MINIMIZER_INDEX=0/1 is a test-only override of that decision.  Nothing here is autouse (round 3's conftest forced
+# the groups on for every test, so the full-size digest tests never ran the route the library ships): a module that wants the groups' code exercised on its
+# small inputs asks for `minimiser_groups_on`, and the tests that must hold on every route take `access_route`.
+@pytest.fixture
+def minimiser_groups_on(monkeypatch):
     if "SAGE2OV_MINIMIZER_INDEX" not in os.environ:
         monkeypatch.setenv("SAGE2OV_MINIMIZER_INDEX", "1")
+
+
+@pytest.fixture(params=["library_default", "groups_on", "groups_off"])
+def access_route(request, monkeypatch, minimiser_groups_on):      # (after the module-level opt-in, whichever way pytest orders them)
+    """the route of the fast kernel's look-ups: what the library picks by itself, the minimiser groups forced on, forced off"""
+    monkeypatch.delenv("SAGE2OV_MINIMIZER_INDEX", raising=False)
+    if request.param != "library_default":
+        monkeypatch.setenv("SAGE2OV_MINIMIZER_INDEX", "1" if request.param == "groups_on" else "0")
+    return request.param

@@ -39,12 +39,21 @@ def test_digest_lookup_by_parameters():
     assert dg.lookup(22, dict(seed=1, genome_len=200_000, n_reads=100_000, read_len=100)) == (None, None)
 
 
+ROUTES = {"library_default": None, "groups_on": "1", "groups_off": "0"}
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["c1", "c2_1m", "c2", "c2_noisy", "c2_repeat", "c3"])
-def test_gpu_reproduces_full_size_digest(name, tmp_path):
+@pytest.mark.parametrize("name,route", [(n, "library_default") for n in ("c1", "c2_1m", "c2", "c2_noisy", "c2_repeat", "c3")] +
+                         [(n, r) for n in ("c2_1m", "c2", "c3") for r in ("groups_on", "groups_off")])
+def test_gpu_reproduces_full_size_digest(name, route, tmp_path, monkeypatch):
     """BASELINE sizes the oracle cannot run inside a test: every number the restatement produced for this input (make_digests.py) must
     come out of the device path -- n_unique, N_ov (the numerator of the headline metric), crc32 of connections / extension records /
-    status classes / packed reads / canonical edge list, the reduce counters, and the md5 of P.graph3."""
+    status classes / packed reads / canonical edge list, the reduce counters, and the md5 of P.graph3.
+    `route`: the access path of the fast kernel's look-ups.  "library_default" is what a user and bench.py get (dev_build_index decides by the data: no
+    minimiser groups at BASELINE configs[1] / configs[2]); the two forced routes keep the other half of the look-up code honest at full size."""
+    monkeypatch.delenv("SAGE2OV_MINIMIZER_INDEX", raising=False)
+    if ROUTES[route] is not None:
+        monkeypatch.setenv("SAGE2OV_MINIMIZER_INDEX", ROUTES[route])
     want = dg.load(name)
     if want is None:
         pytest.skip(f"tests/golden/{name}_digest.json not generated")
@@ -60,7 +69,11 @@ def test_gpu_reproduces_full_size_digest(name, tmp_path):
     got["keys"] = want["keys"]
     bad = dg.compare(got, want)
     assert bad == [], f"{name}: " + "; ".join(bad)
-    if name in ("c1", "c2_1m", "c2", "c3"):
+    if route != "library_default":
+        assert ctx.index_stats().minimiser_groups == (1 if route == "groups_on" else 0), "the route asked for is not the route that ran"
+    elif name in ("c2", "c3"):
+        assert ctx.index_stats().minimiser_groups == 0                    # (what bench.py times: 9.5 % of the reads start a run at 50x coverage, the groups do not pay)
+    if name in ("c1", "c2_1m", "c2", "c3") or want.get("reference_binary"):
         # these digests are pinned on the REFERENCE BINARY itself (oracle/make_digests.py for the small ones, oracle/pin_reference.py for BASELINE
         # configs[1] and configs[2]: `SAGE2 -M 3` on the same reads, 46 minutes for the 50 M-read set): the device path's P.graph3 is the file the
         # reference wrote, and so is its P.reads
@@ -68,9 +81,10 @@ def test_gpu_reproduces_full_size_digest(name, tmp_path):
         rb = want.get("reference_binary")
         if rb:
             assert (got["graph3_md5"], got["graph3_bytes"]) == (rb["graph3_md5"], rb["graph3_bytes"])
-            rp = str(tmp_path / "t.reads"); ctx.reads_save(rp)
-            assert os.path.getsize(rp) == rb["reads_bytes"] and fx.md5_file(rp) == rb["reads_md5"], "P.reads differs from the reference binary's"
-            os.remove(rp)
+            if route == "library_default":                  # (step 1 does not depend on the route; 13 GB of text at configs[2])
+                rp = str(tmp_path / "t.reads"); ctx.reads_save(rp)
+                assert os.path.getsize(rp) == rb["reads_bytes"] and fx.md5_file(rp) == rb["reads_md5"], "P.reads differs from the reference binary's"
+                os.remove(rp)
             st_, ost_ = ctx.reads_stats(), ctx.overlap_stats(); rc = rb["counters"]
             assert (st_.unique_reads, st_.good_reads, ost_.contained_extension, ost_.contained_size, ost_.left_to_explore, ost_.edges_inserted, ost_.transitive_removed) == \
                    (rc["unique_reads"], rc["good_reads"], rc["contained_extension"], rc["contained_size"], rc["left_to_explore"], rc["edges_inserted"], rc["transitive_removed"])

@@ -7,7 +7,7 @@ import sys
 
 import pytest
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("minimiser_groups_on")]      # (small inputs: the groups' half of the look-up code is exercised by request, conftest.py)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -86,3 +86,54 @@ def test_cli_multi_gpu_mode_writes_reference_files(name, gpus, flags, tmp_path):
     for key, lab in (("contained_extension", "Total contained by extension"), ("transitive_removed", "Transitive edge removed")):
         if key in m["counters"]:
             assert f"{lab}: {m['counters'][key]}" in log
+
+
+@pytest.mark.parametrize("gpus,flags,fail_rank", [(3, ["--share-gpu"], 1), (2, ["--share-gpu"], 0), (1, ["--force-multi"], 0)])
+def test_cli_multi_gpu_run_with_a_failed_rank_ends_non_zero(gpus, flags, fail_rank, tmp_path):
+    """A rank that fails (here: injected before its first step, `--fail-rank`) must take the run down -- exit status 1, the failing rank named -- instead of
+    leaving its peers inside a collective or at the thread barrier for ever (sage2ov_multi.cpp; both transports)."""
+    import fixtures as fx, sage2_amd as s2
+    m = fx.golden("g2_clean150_k40")
+    fa = str(tmp_path / "x.fa"); s2.synth_write_fasta(fx.synth_params(m["synth"]), fa)
+    r = subprocess.run([os.path.join(ROOT, "sage2_amd", "sage2ov"), "-f", fa, "-k", str(m["k"]), "-o", str(tmp_path / "out"), "-p", "t", "-M", "3", "-G", str(gpus),
+                        "--fail-rank", str(fail_rank)] + flags, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), timeout=300)
+    out = r.stdout.decode()
+    assert r.returncode not in (0, None) and f"rank {fail_rank}" in out and "failure injected" in out, (r.returncode, out[-2000:])
+    assert not os.path.exists(str(tmp_path / "out" / "t.graph3"))
+
+
+@pytest.fixture(scope="module")
+def configs3_fasta(tmp_path_factory):
+    """BASELINE configs[3]'s reads (= configs[2]'s: 50 M x 150 bp, 150 Mb genome, seed 3) as the FASTA file `sage2ov -f` takes (8.2 GB)"""
+    import digests as dg, fixtures as fx, sage2_amd as s2
+    d = tmp_path_factory.mktemp("configs3")
+    fa = str(d / "c3.fa"); s2.synth_write_fasta(fx.synth_params(dg.CONFIGS["c3"]["synth"]), fa)
+    yield fa
+    os.remove(fa)
+
+
+@pytest.mark.parametrize("ranks", [2, 8])
+def test_configs3_workload_through_the_sharded_path(ranks, configs3_fasta, tmp_path, monkeypatch):
+    """BASELINE configs[3]: the 50 M-read workload (42.5 M unique reads) through the multi-rank code path -- `sage2ov -G ranks`: the C++ driver, one thread and one
+    context per rank, reads and index replicated, the probe pass cut by position range, the four exchanges -- with 2 and 8 ranks sharing the one GPU of the
+    test box (memory-diet mode: eight replicas of a 26 GB context do not fit 288 GB with room to spare).  P.graph3 and P.reads must be the files the REFERENCE
+    BINARY wrote for this input (tests/golden/c3_digest.json: reference_binary), the log's counters the reference's."""
+    import digests as dg, fixtures as fx
+    monkeypatch.delenv("SAGE2OV_MINIMIZER_INDEX", raising=False)              # (the library's own route: what a multi-GPU user gets)
+    want = dg.load("c3"); rb = want["reference_binary"]
+    out = str(tmp_path / "out")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SAGE2OV_MEMORY_DIET="1")
+    r = subprocess.run([os.path.join(ROOT, "sage2_amd", "sage2ov"), "-f", configs3_fasta, "-k", "40", "-o", out, "-p", "t", "-M", "3", "-G", str(ranks), "--share-gpu"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, timeout=1500)
+    assert r.returncode == 0, r.stdout.decode()[-3000:]
+    g3, rd = os.path.join(out, "t.graph3"), os.path.join(out, "t.reads")
+    assert (os.path.getsize(g3), fx.md5_file(g3)) == (rb["graph3_bytes"], rb["graph3_md5"]), "P.graph3 of the sharded run differs from the reference binary's"
+    os.remove(g3)
+    assert (os.path.getsize(rd), fx.md5_file(rd)) == (rb["reads_bytes"], rb["reads_md5"]), "P.reads differs from the reference binary's"
+    os.remove(rd)
+    log = open(os.path.join(out, "t.log")).read()
+    assert f"STEPS 2-3 on {ranks} ranks sharing GPU" in log
+    for key, lab in (("contained_extension", "Total contained by extension"), ("contained_size", "Total contained by size"), ("left_to_explore", "Total left to explore"),
+                     ("edges_inserted", "Total edges inserted"), ("transitive_removed", "Transitive edge removed")):
+        assert f"{lab}: {rb['counters'][key]}" in log, (lab, rb["counters"][key])
+    assert f"Verified overlaps: {want['n_ov']}" in log and f"Edges in the graph: {want['edges']}" in log

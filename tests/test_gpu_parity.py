@@ -8,7 +8,7 @@ import fixtures as fx
 import oracle_lib as ol
 import sage2_amd as s2
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("minimiser_groups_on")]      # (small inputs: the groups' half of the look-up code is exercised by request, conftest.py)
 
 
 def run_gpu(m, bases, off):

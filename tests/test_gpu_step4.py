@@ -7,7 +7,7 @@ import pytest
 import fixtures as fx
 import sage2_amd as s2
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("minimiser_groups_on")]      # (small inputs: the groups' half of the look-up code is exercised by request, conftest.py)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 

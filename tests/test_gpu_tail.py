@@ -13,7 +13,7 @@ import pytest
 import fixtures as fx
 import sage2_amd as s2
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("minimiser_groups_on")]      # (small inputs: the groups' half of the look-up code is exercised by request, conftest.py)
 REF = os.path.join(fx.ROOT, "oracle", "_ref", "SAGE2")
 CLI = os.path.join(fx.ROOT, "sage2_amd", "sage2ov")
 
