@@ -23,6 +23,20 @@ import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+
+
+def csrc_sha1():
+    """sha1 over the whole device side of the library -- sage2ov_device.hip (launchers: grids, chunk sizes, which access path), every kernels_*.inc and the
+    internal header -- in name order.  The recorded PMC figures under profiles/ (probe_traffic.json, probe_insts.json, index_traffic.json) carry the hash of the
+    source they were measured on; bench.py reports them only while the source is the same, null otherwise (round 3 keyed them on two files: a changed launch
+    shape kept the old figure alive)."""
+    import glob, hashlib
+    d = os.path.join(ROOT, "sage2_amd", "csrc")
+    names = sorted(glob.glob(os.path.join(d, "kernels_*.inc")) + [os.path.join(d, "sage2ov_device.hip"), os.path.join(d, "sage2ov_internal.h")])
+    h = hashlib.sha1()
+    for nm in names:
+        h.update(os.path.basename(nm).encode()); h.update(open(nm, "rb").read())
+    return h.hexdigest()
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
@@ -369,9 +383,8 @@ def main():
         if os.path.exists(tj) and args.err_ppm == 0 and world == 1:
             try:
                 te = json.load(open(tj)).get(f"{args.reads}x{args.read_len}_k{args.k}_seed{args.seed}", {})
-                import hashlib
-                sha = hashlib.sha1(b"".join(open(os.path.join(ROOT, "sage2_amd", "csrc", nm), "rb").read() for nm in ("kernels_probe_fast.inc", "kernels_common.inc"))).hexdigest()
-                if te.get("kernel_source_sha1") == sha:              # a PMC pass of THIS kernel source; anything older is stale: null
+                sha = csrc_sha1()
+                if te.get("kernel_source_sha1") == sha:              # a PMC pass of THIS device source (every kernel file and the launchers: grids and access paths move the traffic too); anything older is stale: null
                     traffic, traffic_src = te.get("bytes_per_launch"), te.get("source")
             except Exception:
                 traffic = None
@@ -382,9 +395,8 @@ def main():
         ij = os.path.join(ROOT, "profiles", "probe_insts.json")
         if os.path.exists(ij) and args.err_ppm == 0 and world == 1 and kern_ms > 0:
             try:
-                import hashlib
                 ie = json.load(open(ij)).get(f"{args.reads}x{args.read_len}_k{args.k}_seed{args.seed}", {})
-                sha = hashlib.sha1(b"".join(open(os.path.join(ROOT, "sage2_amd", "csrc", nm), "rb").read() for nm in ("kernels_probe_fast.inc", "kernels_common.inc"))).hexdigest()
+                sha = csrc_sha1()
                 if ie.get("kernel_source_sha1") == sha:
                     peak = 256 * 4 * 2.4e9 / 2.0
                     achieved = ie["valu_per_read"] * st.unique_reads / (kern_ms * 1e-3)
