@@ -631,6 +631,7 @@ static ProbeArgs base_args(Device* d) {
     A.right = d->right; A.left = d->left; A.conn = d->conn; A.cflag = d->cflag; A.status = d->status; A.counters = d->d_counters;
     A.mi1 = d->mi1; A.TL = d->TL; A.krec = d->krec; A.uniL = d->uniL;
     A.chunkShift = (u32)FAST_CHUNK_LOG;      // (plan_fast_grid may double the positions per block visit)
+    A.noRun = getenv("SAGE2OV_NO_RUN_MODE") ? 1u : 0u;
     return A;
 }
 
@@ -728,8 +729,8 @@ int dev_probe(Device* d, uint64_t lo, uint64_t hi, std::string& err) {
         // (positions [lo, hi) of the locality order: consecutive items are neighbours in the genome AND in the read store)
 #ifdef SAGE2OV_STAMPS
         static u64* d_stamps = nullptr;
-        if (!d_stamps) HIPCHK(hipMalloc(&d_stamps, 24 * sizeof(u64)));
-        HIPCHK(hipMemsetAsync(d_stamps, 0, 24 * sizeof(u64), d->stream)); A.stamps = d_stamps;
+        if (!d_stamps) HIPCHK(hipMalloc(&d_stamps, 32 * sizeof(u64)));
+        HIPCHK(hipMemsetAsync(d_stamps, 0, 32 * sizeof(u64), d->stream)); A.stamps = d_stamps;
 #endif
         // Which kernel?  The one that carries the state machine for inconsistent reads (TAIL = 1) is 10 % slower on every read; on error-free
         // data a read in a thousand needs it.  So the first 1/128 of the range runs without it (TAIL = 0: such reads are listed), the share of
@@ -830,10 +831,11 @@ int dev_probe(Device* d, uint64_t lo, uint64_t hi, std::string& err) {
         d->tm.probe_kernel_ms += kms; d->tm.probe_launches++;
         d->tm.slow_reads += nslow;
 #ifdef SAGE2OV_STAMPS
-        { u64 st[24]; HIPCHK(hipMemcpy(st, d_stamps, sizeof st, hipMemcpyDeviceToHost)); u64 tot = 0; for (int x = 0; x < 24; x++) if (x < 10 || x >= 16) tot += st[x];
+        { u64 st[32]; HIPCHK(hipMemcpy(st, d_stamps, sizeof st, hipMemcpyDeviceToHost)); u64 tot = 0; for (int x = 0; x < 24; x++) if (x < 10 || x >= 16) tot += st[x];
           // stages 0-9 in order of the code; 16 = slot -> window -> entry (before the gathers), 17 = reach, 18 = broadcast of the speculated reads, 19 = compares (8 = what follows them)
           fprintf(stderr, "[stamps] kernel %.2f ms; share of wave cycles (cycles per read):", kms); for (int x = 0; x < 24; x++) if (x < 10 || (x >= 16 && x < 21)) fprintf(stderr, " %d:%.1f%% (%.0f)", x, 100.0 * (double)st[x] / (double)tot, st[10] ? (double)st[x] / (double)st[10] : 0.0);
-          fprintf(stderr, "; window reuse: %llu of %llu reads (same minimiser strand as the previous read: %llu), mean shift %.1f\n", (unsigned long long)st[11], (unsigned long long)st[10], (unsigned long long)st[13], st[11] ? (double)st[12] / (double)st[11] : 0.0); }
+          fprintf(stderr, "; window reuse: %llu of %llu reads (same minimiser strand as the previous read: %llu), mean shift %.1f\n", (unsigned long long)st[11], (unsigned long long)st[10], (unsigned long long)st[13], st[11] ? (double)st[12] / (double)st[11] : 0.0);
+          fprintf(stderr, "[stamps] run mode: %llu reads off the frame, %llu runs ended on a read the general path took\n", (unsigned long long)st[24], (unsigned long long)st[25]); }
 #endif
         if (launched && nslow) {                                              // ambiguous / overflowing reads: sequential state machine
             ProbeArgs B = base_args(d); B.ids = list; B.n_ids = nslow;
