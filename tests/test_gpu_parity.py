@@ -1010,3 +1010,31 @@ def test_memory_diet_mode_matches_reference(name, tmp_path, monkeypatch):
         arena = c.debug_meminfo()["arena"]; c.close()
         return arena
     assert run(True) < run(False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("run_mode", ["on", "off"])
+@pytest.mark.parametrize("pd,k", [
+    (dict(seed=171, genome_len=90000, n_reads=30000, read_len=150, err_ppm=0), 40),                            # 50x, clean: nearly every read of a run is answered off the frame
+    (dict(seed=172, genome_len=90000, n_reads=30000, read_len=150, err_ppm=60), 40),                           # a read error now and then: runs end on a candidate that does not verify and start again
+    (dict(seed=173, genome_len=40000, n_reads=40000, read_len=100, err_ppm=0), 21),                            # 100x of 100-base reads, 80 windows, the 4-word layout; many reads past 128 slots (wide form: 256-slot ring)
+    (dict(seed=174, genome_len=200000, n_reads=16000, read_len=150, err_ppm=0), 55),                           # 12x: short runs, long shifts (beyond RUN_DMAX), k = 55
+    (dict(seed=175, genome_len=60000, n_reads=20000, read_len=150, err_ppm=0, n_repeat_families=3, repeat_len=300, repeat_copies=5), 40),   # repeats: candidates that share a key but not the frame
+    (dict(seed=176, genome_len=60000, n_reads=20000, read_len=150, err_ppm=0), 64),                            # k = 64: the widest key whose gates do not depend on the window
+    (dict(seed=177, genome_len=60000, n_reads=20000, read_len=150, err_ppm=0), 70),                            # k = 70 > 64: no run mode (hash string of 64, gates by window): the general path only
+    (dict(seed=178, genome_len=9000, n_reads=30000, read_len=150, err_ppm=0), 40),                             # 500x: duplicates collapse, every window a bucket of many entries, rings fill up
+])
+def test_run_mode_of_the_fast_kernel_is_exact(pd, k, run_mode, monkeypatch):
+    """Run mode (kernels_probe_fast.inc: the reads of a run of the locality order answered off a verified frame and a ring of verified slots) on and off
+    (SAGE2OV_NO_RUN_MODE): the oracle's extension records, connection counts, edges and counters either way; and with the probe sampled on these small inputs,
+    so that the sample launch, the rest and the listed reads all run their forms."""
+    monkeypatch.delenv("SAGE2OV_MINIMIZER_INDEX", raising=False)          # (the library's own route on small inputs: the uniform table; the groups' route is the module default elsewhere)
+    monkeypatch.setenv("SAGE2OV_PROBE_SAMPLE_MIN", "2048")
+    if run_mode == "off":
+        monkeypatch.setenv("SAGE2OV_NO_RUN_MODE", "1")
+    bases, off = fx.make_reads(pd)
+    m = dict(k=k)
+    g, o = run_gpu(m, bases, off), run_oracle(m, bases, off)
+    assert_equals_oracle(g, o)
+    g.run_steps23(); assert_equals_oracle(g, o)                            # (a second pass over the resident reads)
+    g.close(); o.close()
