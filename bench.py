@@ -428,13 +428,33 @@ def main():
                          # memory-side bytes per launch (PMC, profiles/probe_traffic.json) over the live kernel time: what the kernel really pulls
                          "traffic_achieved": (traffic * share / (kern_ms * 1e-3) / 1e9) if (traffic and kern_ms > 0) else None,
                          "traffic_frac": (traffic * share / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and kern_ms > 0) else None,
-                         "limiter": "memory-side line rate and instruction issue together: 65 line requests of 128 B per read behind the L2 (x2.0 of the algorithmic bytes = 0.74 of the HBM peak, part of it served by the Infinity Cache) and about 680 VALU + 485 scalar wave-instructions per read at EIGHT waves per SIMD (end of round 3: sequential-groups form, 64 VGPRs; locality order on all 32 bits of the minimiser hash, every look-up through the uniform table) (DESIGN.md 5.2)",
+                         "limiter": "instruction issue: since round 4 the kernel answers 87 % of the reads in RUN MODE (off a verified frame and a ring of verified slots: DESIGN.md 5.2) -- 497 VALU + 332 scalar wave-instructions and 28.5 memory-side line requests of 128 B per read (round 3: 691 + 484 and 62), i.e. the memory side is at x1.0 of the algorithmic bytes and 2.6 TB/s; what is left is the 13 % of reads that start a run (the general path: 111 table look-ups, 62 gathered candidates) and the issue slots of the run-mode path",
                          # a probe pass is up to three launches of the kernel: a sample of 1/128 of the range, the rest (the instantiation the sample picked), and the
                          # few reads the first two listed; kernel_ms and the bytes are those of the whole pass (sum over its launches)
                          "valu": valu,
                          "kernel_ms": kern_ms, "kernel_launches_per_pass": pk_f / max(pk_n, 1), "algorithmic_bytes_per_launch": a_probe * share,
                          "whole_path_achieved": a_total / (elapsed / args.steps) / 1e9, "whole_path_frac": a_total / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
         }
+        # the second-largest phase gets a roofline block of its own: the index build (locality order + store, tuples, partition, windows) against its
+        # algorithmic bytes N (B + 4 x 16) -- read every read once, write four slots -- and, when a PMC pass of THIS source is on record, its memory-side bytes
+        B_ = (args.read_len + 3) // 4
+        a_index = st.unique_reads * (B_ + 4 * SLOT_ALG)
+        ix_ms = res["phases_ms"]["index_ms"]
+        ix_traffic, ix_src = None, None
+        xj = os.path.join(ROOT, "profiles", "index_traffic.json")
+        if os.path.exists(xj) and args.err_ppm == 0 and world == 1:
+            try:
+                xe = json.load(open(xj)).get(f"{args.reads}x{args.read_len}_k{args.k}_seed{args.seed}", {})
+                if xe.get("kernel_source_sha1") == csrc_sha1():
+                    ix_traffic, ix_src = xe.get("bytes_per_step"), xe.get("source")
+            except Exception:
+                ix_traffic = None
+        res["roofline_index"] = {"bound": "hbm", "kernel": "index build: k_minimizer, k_pt_hist / k_pt_scatter (order: 5 passes, table: 2), k_loc_index, k_loc_scatter, k_ix_tuples, k_ix_window",
+                                 "ms": ix_ms, "algorithmic_bytes_per_step": a_index, "achieved": (a_index / (ix_ms * 1e-3) / 1e9) if ix_ms > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": (a_index / (ix_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if ix_ms > 0 else None, "traffic": ix_traffic,
+                                 "traffic_source": ix_src and f"recorded: {ix_src} (rocprofv3 PMC passes of this workload, not of this run)",
+                                 "traffic_frac": (ix_traffic / (ix_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (ix_traffic and ix_ms > 0) else None,
+                                 "limiter": "a sort: the passes are bound per tuple (stable ranking: nine ballots per 64 tuples, two dependent LDS round trips), not per byte (DESIGN.md 5.1)"}
         def step4_of(c):
             """step 4 on the graph the timed steps left in HBM: outside the timed region, two runs, the second reported"""
             t4 = time.perf_counter(); c.graph_simplify(); w41 = time.perf_counter() - t4

@@ -687,7 +687,7 @@ static unsigned plan_fast_grid(ProbeArgs& A, u64 n, bool writesHits = false) {
     // positions per block visit: twice FAST_CHUNK for launches big enough that the coarser grid does not show (kernels_probe_fast.inc: 24 M positions and more;
     // SAGE2OV_FAST_CHUNK_SHIFT = 7 / 8 overrides); launches that write hits out keep the small size
     u32 cs = (u32)FAST_CHUNK_LOG + ((n >= 24000000ull && !writesHits) ? 1u : 0u);
-    if (const char* ec = getenv("SAGE2OV_FAST_CHUNK_SHIFT")) cs = (u32)std::max(FAST_CHUNK_LOG, std::min(FAST_CHUNK_LOG + 1, atoi(ec)));
+    if (const char* ec = getenv("SAGE2OV_FAST_CHUNK_SHIFT")) cs = (u32)std::max(FAST_CHUNK_LOG, std::min(FAST_CHUNK_LOG + 3, atoi(ec)));
     A.chunkShift = cs;
     const u64 CH = 1ull << cs, C = (n + CH - 1) / CH;
     if (writesHits || uniform || C <= PB * 8) {
