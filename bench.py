@@ -203,16 +203,28 @@ def spawn_ranks(n):
         env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    # rank 0's line is drained by a reader thread while ALL children are polled: a rank >= 1 that dies leaves rank 0 inside a collective with its stdout open, and a
+    # parent blocked in procs[0].stdout.read() would never get to the terminate loop
+    import threading
+    buf = []
+    rd = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True); rd.start()
     rc = 0
-    out = procs[0].stdout.read().decode()
+    while any(pr.poll() is None for pr in procs):
+        for r, pr in enumerate(procs):
+            c = pr.poll()
+            if c and not rc:
+                rc = c
+                log(f"[bench] rank {r} exited with code {c}")
+                for q in procs:                              # the exact children started above, nothing else
+                    if q.poll() is None:
+                        q.terminate()
+        time.sleep(0.05)
     for r, pr in enumerate(procs):
         c = pr.wait()
         if c and not rc:
-            rc = c
-            log(f"[bench] rank {r} exited with code {c}")
-            for q in procs:                                  # the exact children started above, nothing else
-                if q.poll() is None:
-                    q.terminate()
+            rc = c; log(f"[bench] rank {r} exited with code {c}")
+    rd.join(timeout=10)
+    out = (buf[0] if buf else b"").decode()
     sys.stdout.write(out); sys.stdout.flush()
     return rc
 

@@ -481,7 +481,7 @@ int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t
     *rebuilds = 0;
     const bool timing = getenv("SAGE2OV_TIMING") != nullptr; auto tp = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) { if (!timing) return; hipStreamSynchronize(d->stream); auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[index] %-34s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - tp).count()); tp = t; };
-    u64 c[9];
+    u64 c[9]; u32 ixCntBits = (u32)IXW_CNT_BITS_DEFAULT;
     for (int attempt = 0;; attempt++) {
         HIPCHK(hipMemsetAsync(d->d_counters + 8, 0, 10 * sizeof(u64), d->stream));
         // ---- tuples of the 4N entries, sorted by the window of their home slot
@@ -501,7 +501,7 @@ int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t
         }
         // ---- the windows of the uniform table, built in LDS; group tuples into the free buffer set
         IxWinArgs A; A.T = B.E[cur]; A.W = B.W; A.winOff = winOff; A.nW = (u32)nW; A.slots = d->slots; A.csr = d->csr;
-        A.counters = d->d_counters + 8; A.big = big; A.big_cap = big_cap; A.idOf = d->idOf; A.G = wantMI ? B.E[cur ^ 1] : nullptr; A.wh = nullptr;     // (group tuples, 12 bytes each, into the free 16-byte buffer)
+        A.counters = d->d_counters + 8; A.big = big; A.big_cap = big_cap; A.idOf = d->idOf; A.G = wantMI ? B.E[cur ^ 1] : nullptr; A.wh = nullptr; A.cntBits = ixCntBits;     // (group tuples, 12 bytes each, into the free 16-byte buffer)
         // (the scratch words of heavy windows need a buffer of their own)
         // one word per SURPLUS tuple of a heavy window (more than 3072 tuples where the mean is 2048: keys in thousands of reads); small inputs get the
         // worst case (every tuple in one window), big ones an eighth of it
@@ -513,7 +513,10 @@ int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t
         u64 c9 = 0; HIPCHK(hipMemcpyAsync(&c9, d->d_counters + 8 + 9, sizeof c9, hipMemcpyDeviceToHost, d->stream));
         HIPCHK(hipStreamSynchronize(d->stream));
         lap("table windows"); mem_sample(d);
-        if (c[8]) { char b_[256]; snprintf(b_, sizeof b_, "index build: %llu table windows overflowed, %llu keys occur in more than 1 M reads, %llu heavy windows found no scratch (cursor %llu of %llu)",
+        if (c[8] && (c[8] & 0xFFFFFull) == 0 && (c[8] >> 40) == 0 && ixCntBits == (u32)IXW_CNT_BITS_DEFAULT) {      // only the per-key counter ran over: again, with 30 bits of count
+            if (timing) fprintf(stderr, "[index] a key occurs in more than 2^20 reads: building again with the wide counter split\n");
+            ixCntBits = (u32)IXW_CNT_BITS_WIDE; attempt--; continue; }
+        if (c[8]) { char b_[256]; snprintf(b_, sizeof b_, "index build: %llu table windows overflowed, %llu keys occur in more than 2^30 reads, %llu heavy windows found no scratch (cursor %llu of %llu)",
                              (unsigned long long)(c[8] & 0xFFFFF), (unsigned long long)((c[8] >> 20) & 0xFFFFF), (unsigned long long)(c[8] >> 40), (unsigned long long)c9, (unsigned long long)A.wh_cap);
                     err = b_; return SAGE2OV_ERR_LIMIT; }
         if (c[2] > big_cap) { err = "too many long buckets"; return SAGE2OV_ERR_LIMIT; }

@@ -1038,3 +1038,21 @@ def test_run_mode_of_the_fast_kernel_is_exact(pd, k, run_mode, monkeypatch):
     assert_equals_oracle(g, o)
     g.run_steps23(); assert_equals_oracle(g, o)                            # (a second pass over the resident reads)
     g.close(); o.close()
+
+
+@pytest.mark.gpu
+def test_a_key_in_more_than_2_to_20_reads(monkeypatch):
+    """One k-mer as the prefix of 1.15 M different reads (an adaptor, a low-complexity stretch at human scale): the bucket's counter in the window kernel has 20 bits by
+    default; the build notices the overflow and runs again with 30 bits of count instead of failing with SAGE2OV_ERR_LIMIT.  The bucket is long
+    (hashTable.cpp:111-123: never found), its reads find each other through their other keys or not at all: the oracle's records, edges and counters."""
+    rng = np.random.default_rng(20260401)
+    n, L, k = 1_150_000, 64, 21
+    pre = np.frombuffer(b"ACGTTGCAAGGCTTACGATCC", dtype=np.uint8)
+    tail = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=(n, L - len(pre)))]
+    bases = np.concatenate([np.broadcast_to(pre, (n, len(pre))), tail], axis=1).reshape(-1).copy()
+    off = (np.arange(n + 1, dtype=np.uint64) * np.uint64(L))
+    m = dict(k=k)
+    g, o = run_gpu(m, bases, off), run_oracle(m, bases, off)
+    assert g.index_stats().long_buckets >= 1
+    assert_equals_oracle(g, o)
+    g.close(); o.close()
