@@ -480,6 +480,7 @@ def main():
                 saved = os.environ.get("SAGE2OV_MINIMIZER_INDEX")
                 os.environ["SAGE2OV_MINIMIZER_INDEX"] = "0"
                 try:
+                    ctx.options_reload()                             # (the library reads its switches once, at context creation)
                     ctx.timings_reset(); ctx.index_build(); ctx.overlap_probe_shard(); ta = ctx.timings()
                     alt = {"index_ms": ta.index_ms, "probe_ms": ta.probe_ms}
                 finally:
@@ -487,6 +488,7 @@ def main():
                         os.environ.pop("SAGE2OV_MINIMIZER_INDEX", None)
                     else:
                         os.environ["SAGE2OV_MINIMIZER_INDEX"] = saved
+                    ctx.options_reload()
                 ctx.run_steps23()                                    # (back to the state the step-4 figures below start from)
             res["scaling_model"] = scaling_model(st.unique_reads, ost.edges, ms_per_step, res["phases_ms"], alt)
             if alt:

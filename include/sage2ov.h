@@ -56,6 +56,10 @@ typedef struct sage2ov_config {
 int  sage2ov_ctx_create(const sage2ov_config* cfg, sage2ov_ctx** out);
 void sage2ov_ctx_destroy(sage2ov_ctx* ctx);
 const char* sage2ov_last_error(const sage2ov_ctx* ctx);   /* ctx may be NULL: error of the last failed create */
+/* The library's SAGE2OV_* environment switches (test-only route overrides, grid sweeps, diagnostics -- the reference has none,
+ * main.cpp:384-521 takes flags only) are read ONCE, when the context is created; no step reads the environment.  This call takes a new snapshot: for tests
+ * and diagnostics that change a switch between two steps of one context. */
+int sage2ov_options_reload(sage2ov_ctx* ctx);
 const char* sage2ov_version(void);
 
 /* ---- STEP 1: ReadLoader (inputReader/readLoader.h:44-55) ---- */

@@ -215,6 +215,10 @@ class Context:
     def hashtable_save(self, path):
         self._chk(lib().sage2ov_hashtable_save(self._h, path.encode()))
 
+    def options_reload(self):
+        """re-read the SAGE2OV_* environment switches (the library reads them once, when the context is created)"""
+        self._chk(lib().sage2ov_options_reload(self._h))
+
     def index_lookup(self, v0, v1, cap=128):
         key = (C.c_uint64 * 2)(v0, v1)
         ent = (C.c_uint64 * cap)()

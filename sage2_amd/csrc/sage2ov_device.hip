@@ -43,6 +43,7 @@ enum { WS_SLOTS, WS_CNT, WS_WHERE, WS_BIG, WS_CSR, WS_SLOW, WS_NEED, WS_DEG, WS_
        WS_PT_K0, WS_PT_K1, WS_PT_P0, WS_PT_P1, WS_PT_M0, WS_PT_M1, WS_PT_CNT, WS_PT_BASE, WS_PT_OFF, WS_PT_GOFF, WS_RR_LOC, WS_RR_RANKL, WS_LOC_READS, WS_LOC_IDOF, WS_LOC_POSOF, WS_LOC_STATUS, WS_ORG_GFLAG, WS_ORG_GPOS, WS_LOC_META, WS_SLOW2, WS_RA_ENT32, WS_RA_SPLIT, WS_PRE_BASE, WS_PRE_NONE, WS_COUNT };   // ids of the workspace arena (Device::ws)
 struct Device {
     int ordinal = 0;
+    Options opt;                 // the environment switches, as the context read them when it was created (sage2ov_internal.h)
     hipStream_t stream = nullptr;
     hipEvent_t ev[8] = {};
     // reads
@@ -103,7 +104,7 @@ static void ws_free(Device* d, int id) { Device::Buf& b = d->ws[id]; if (b.p) hi
 static void decide_diet(Device* d) {
     size_t fr = 0, to = 0; d->diet = false;
     if (hipMemGetInfo(&fr, &to) == hipSuccess && to) d->diet = (double)(d->N + 1) * 640.0 > 0.7 * (double)to;
-    if (const char* ev = getenv("SAGE2OV_MEMORY_DIET")) d->diet = atoi(ev) != 0;
+    if (const char* ev = d->opt.get("SAGE2OV_MEMORY_DIET")) d->diet = atoi(ev) != 0;
 }
 static void mem_sample(Device* d) { size_t fr = 0, to = 0; if (hipMemGetInfo(&fr, &to) == hipSuccess) d->memLow = std::min<u64>(d->memLow, (u64)fr); }
 #define WS(var, type, id, count)                                                                     \
@@ -132,7 +133,8 @@ static void mem_sample(Device* d) { size_t fr = 0, to = 0; if (hipMemGetInfo(&fr
 static inline unsigned grid_for(u64 n, unsigned block) { return (unsigned)std::max<u64>(1, (n + block - 1) / block); }
 static inline unsigned grid_for_capped(u64 n, unsigned block) { return (unsigned)std::max<u64>(1, std::min<u64>((n + block - 1) / block, ((1ull << 32) / block) - 1)); }
 
-Device* dev_create(int ordinal, std::string& err) {
+void dev_set_options(Device* d, const Options& opt) { d->opt = opt; }
+Device* dev_create(int ordinal, const Options& opt, std::string& err) {
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count == 0) { err = std::string("no HIP device available: ") + hipGetErrorString(e); return nullptr; }
@@ -140,15 +142,15 @@ Device* dev_create(int ordinal, std::string& err) {
     if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) dev = 0; }
     if (dev >= count) { err = "device ordinal out of range"; return nullptr; }
     if (hipSetDevice(dev) != hipSuccess) { err = "hipSetDevice failed"; return nullptr; }
-    Device* d = new Device(); d->ordinal = dev;
+    Device* d = new Device(); d->ordinal = dev; d->opt = opt;
     if (hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess) { err = "hipStreamCreate failed"; delete d; return nullptr; }
-    { const char* tb = getenv("SAGE2OV_TEST_TAG_BITS"); const int nb = tb ? atoi(tb) : 24;
+    { const char* tb = d->opt.get("SAGE2OV_TEST_TAG_BITS"); const int nb = tb ? atoi(tb) : 24;
       const u32 mask = (nb >= 1 && nb < 24) ? ((1u << nb) - 1u) : 0xFFFFFFu;
       if (hipMemcpyToSymbol(HIP_SYMBOL(g_tag_mask), &mask, sizeof mask) != hipSuccess) { err = "tag mask upload failed"; delete d; return nullptr; }
-      const char* mb = getenv("SAGE2OV_TEST_MTAG_BITS"); const int nm = mb ? atoi(mb) : 24;
+      const char* mb = d->opt.get("SAGE2OV_TEST_MTAG_BITS"); const int nm = mb ? atoi(mb) : 24;
       const u32 mmask = (nm >= 1 && nm < 24) ? ((1u << nm) - 1u) : 0xFFFFFFu;
       if (hipMemcpyToSymbol(HIP_SYMBOL(g_mtag_mask), &mmask, sizeof mmask) != hipSuccess) { err = "tag mask upload failed"; delete d; return nullptr; }
-      const char* fb = getenv("SAGE2OV_TEST_FP_BITS"); const int nf = fb ? atoi(fb) : 20;
+      const char* fb = d->opt.get("SAGE2OV_TEST_FP_BITS"); const int nf = fb ? atoi(fb) : 20;
       const u32 fmask = (nf >= 0 && nf < 20) ? ((1u << nf) - 1u) : 0xFFFFFu;
       if (hipMemcpyToSymbol(HIP_SYMBOL(g_fp_mask), &fmask, sizeof fmask) != hipSuccess) { err = "fingerprint mask upload failed"; delete d; return nullptr; } }
     for (auto& ev : d->ev) hipEventCreate(&ev);
@@ -218,7 +220,7 @@ int dev_organize_reads(Device* d, const uint64_t* pool, uint64_t pool_words, con
     struct EvPair { hipEvent_t a = nullptr, b = nullptr; ~EvPair() { if (a) hipEventDestroy(a); if (b) hipEventDestroy(b); } } evp;   // (destroyed on every return path)
     HIPCHK(hipEventCreate(&evp.a)); HIPCHK(hipEventCreate(&evp.b));
     const hipEvent_t e0 = evp.a, e1 = evp.b;
-    const bool timing = getenv("SAGE2OV_TIMING") != nullptr; auto tp = std::chrono::steady_clock::now();
+    const bool timing = d->opt.get("SAGE2OV_TIMING") != nullptr; auto tp = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) { if (!timing) return; hipStreamSynchronize(d->stream); auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[step 1/device] %-30s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(t - tp).count()); tp = t; };
     HIPCHK(hipEventRecord(e0, d->stream));
     // ASCII input (sage2ov_reads_add_ascii): filter, 2-bit pack and canonical orientation on the device (utils.cpp:144-166, :96-119, readLoader.cpp:195)
@@ -269,7 +271,7 @@ int dev_organize_reads(Device* d, const uint64_t* pool, uint64_t pool_words, con
         HIPCHK(hipMemsetAsync(flag, 0, sizeof(u32), d->stream));
         hipLaunchKernelGGL(k_org_longrun, dim3(grid_for(n, 256)), dim3(256), 0, d->stream, ka, (u64)n, flag);
         HIPCHK(hipMemcpyAsync(&longrun, flag, sizeof longrun, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
-        if (longrun || getenv("SAGE2OV_TEST_FULL_SORT")) {
+        if (longrun || d->opt.get("SAGE2OV_TEST_FULL_SORT")) {
             // many reads share their first 32 bases: order on every word instead (stable LSD radix, last word first; the pairs arrive
             // sorted by the first word, which the last eight passes simply reproduce)
             for (int c = S - 1; c >= 0; c--) {
@@ -359,7 +361,7 @@ static int build_locality_store(Device* d, std::string& err) {
     WS(me, unsigned short, WS_LOC_META, N + 2);
     d->readsLoc = rl; d->idOf = io; d->posOf = po; d->statusP = sp; d->metaP = me;
     const u32* order = nullptr;
-    if (N && !getenv("SAGE2OV_NO_LOCALITY")) { int rc = build_locality_order(d, 1, N + 1, &order, err); if (rc) return rc; }
+    if (N && !d->opt.get("SAGE2OV_NO_LOCALITY")) { int rc = build_locality_order(d, 1, N + 1, &order, err); if (rc) return rc; }
     HIPCHK(hipMemsetAsync(d->d_runStarts, 0, 64 * sizeof(u64), d->stream));                   // run starts of the order (k_loc_index)
     hipLaunchKernelGGL(k_loc_index, dim3(grid_for(std::max<u64>(N, 1), 256)), dim3(256), 0, d->stream, order, (u64)N, io, po, me, (unsigned long long*)d->d_runStarts);
     d->runStartsValid = order != nullptr;
@@ -436,7 +438,7 @@ int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t
     }
     d->T = std::max<u64>(IX_W, (8 * N + IX_W - 1) / IX_W * IX_W);            // load <= 0.5, as hashTable.cpp:83 sizes it; whole windows
     // (tests: SAGE2OV_TEST_TABLE_SLOTS forces a larger table, e.g. beyond 2^32 slots -- slot indices are 64-bit, pair indices and window ids 32-bit)
-    if (const char* ev = getenv("SAGE2OV_TEST_TABLE_SLOTS")) { const u64 want = strtoull(ev, nullptr, 10); if (want > d->T) d->T = (want + IX_W - 1) / IX_W * IX_W; }
+    if (const char* ev = d->opt.get("SAGE2OV_TEST_TABLE_SLOTS")) { const u64 want = strtoull(ev, nullptr, 10); if (want > d->T) d->T = (want + IX_W - 1) / IX_W * IX_W; }
     if ((d->T >> 1) >= (1ull << 32)) { err = "table too large: more than 2^32 slot pairs"; return SAGE2OV_ERR_LIMIT; }
     const u64 nW = d->T / IX_W; const u32 n = (u32)(4 * N);
     const u32 big_cap = 1u << 20;
@@ -458,9 +460,9 @@ int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t
     }
     const double f_ = d->runStartFrac, sizeFactor = N >= 20000000ull ? 1.0 : 0.72;
     bool wantMI = !d->diet && N >= 2000000ull && d->probeShare * sizeFactor * RUN_START_RULE(f_) >= 1.0;
-    if (getenv("SAGE2OV_TIMING")) fprintf(stderr, "[index] reads without a predecessor in the locality order: %.1f %% -> minimiser groups %s\n", 100.0 * f_, wantMI ? "built" : "not built");
-    if (const char* ev = getenv("SAGE2OV_MINIMIZER_INDEX")) wantMI = atoi(ev) != 0;
-    if (getenv("SAGE2OV_NO_MINIMIZER_INDEX") || (d->h - std::min(d->h, 16) + 1) < 8) wantMI = false;
+    if (d->opt.get("SAGE2OV_TIMING")) fprintf(stderr, "[index] reads without a predecessor in the locality order: %.1f %% -> minimiser groups %s\n", 100.0 * f_, wantMI ? "built" : "not built");
+    if (const char* ev = d->opt.get("SAGE2OV_MINIMIZER_INDEX")) wantMI = atoi(ev) != 0;
+    if (d->opt.get("SAGE2OV_NO_MINIMIZER_INDEX") || (d->h - std::min(d->h, 16) + 1) < 8) wantMI = false;
     u64 TL = 0; int tlBits = 0; u64 gW = 0;
     // >= 3N group words (round 3; 2N before): a group window takes 256 x MIW_R = 2048 group tuples in registers and ~3N distinct keys spread over TL / 2048 windows, so with
     // TL in [2N, 3N) most windows overflowed into the global scratch, the scratch ran out, and the groups were built and then given up ("crowded") for every read set
@@ -479,7 +481,7 @@ int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t
         WS(go, u32, WS_PT_GOFF, gW + 3); gOff = go;
     }
     *rebuilds = 0;
-    const bool timing = getenv("SAGE2OV_TIMING") != nullptr; auto tp = std::chrono::steady_clock::now();
+    const bool timing = d->opt.get("SAGE2OV_TIMING") != nullptr; auto tp = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) { if (!timing) return; hipStreamSynchronize(d->stream); auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[index] %-34s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - tp).count()); tp = t; };
     u64 c[9]; u32 ixCntBits = (u32)IXW_CNT_BITS_DEFAULT;
     for (int attempt = 0;; attempt++) {
@@ -492,7 +494,7 @@ int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t
         int cur = 0;
         { int rc = partition_by_window(d, B, 0, n, IX_WPLOG, nW, doHist != 0, cnt, base, winOff, &cur, err); if (rc) return rc; }
         lap("partition by table window");
-        if (getenv("SAGE2OV_VERIFY_PARTITION") && n) {
+        if (d->opt.get("SAGE2OV_VERIFY_PARTITION") && n) {
             u64* vo = nullptr; HIPCHK(hipMalloc(&vo, 3 * sizeof(u64))); HIPCHK(hipMemsetAsync(vo, 0, 3 * sizeof(u64), d->stream));
             hipLaunchKernelGGL(k_pt_verify, dim3(grid_for(n, 256)), dim3(256), 0, d->stream, B.E[cur], n, IX_WPLOG, (u32)B.W, winOff, (u32)nW, vo);
             u64 hv[3]; HIPCHK(hipMemcpyAsync(hv, vo, sizeof hv, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream)); hipFree(vo);
@@ -506,7 +508,7 @@ int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t
         // one word per SURPLUS tuple of a heavy window (more than 3072 tuples where the mean is 2048: keys in thousands of reads); small inputs get the
         // worst case (every tuple in one window), big ones an eighth of it
         { const u64 whCap = n <= (64u << 20) ? nAlloc : nAlloc / 8; WS(whs, u64, WS_WHERE, whCap); A.wh = whs; A.wh_cap = whCap; }
-        static const u64 ixPerCu = getenv("SAGE2OV_IXW_GRID_PER_CU") ? std::max(1, atoi(getenv("SAGE2OV_IXW_GRID_PER_CU"))) : 6;
+        const u64 ixPerCu = d->opt.get("SAGE2OV_IXW_GRID_PER_CU") ? std::max(1, atoi(d->opt.get("SAGE2OV_IXW_GRID_PER_CU"))) : 6;
         hipLaunchKernelGGL(k_ix_window, dim3((unsigned)std::min<u64>(nW, 256ull * ixPerCu)), dim3(IXW_T), 0, d->stream, A);      // persistent: two rounds of 3 workgroups per CU, each with ONE pair of statistics atomics
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(c, d->d_counters + 8, sizeof c, hipMemcpyDeviceToHost, d->stream));
@@ -536,7 +538,7 @@ int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t
                 lap("partition by group window");
                 MiWinArgs MA; MA.G = G.E[gcur]; MA.gOff = gOff; MA.gW = (u32)gW; MA.tlBits = tlBits; MA.mi1 = mi1; MA.krec = krec; MA.counters = d->d_counters + 8; MA.wh = A.wh; MA.wh_cap = A.wh_cap;
                 HIPCHK(hipMemsetAsync(d->d_counters + 8 + 9, 0, sizeof(u64), d->stream));                  // (the scratch cursor starts over)
-                static const u64 miPerCu = getenv("SAGE2OV_MIW_GRID_PER_CU") ? std::max(1, atoi(getenv("SAGE2OV_MIW_GRID_PER_CU"))) : 8;
+                const u64 miPerCu = d->opt.get("SAGE2OV_MIW_GRID_PER_CU") ? std::max(1, atoi(d->opt.get("SAGE2OV_MIW_GRID_PER_CU"))) : 8;
                 hipLaunchKernelGGL(k_mi_window, dim3((unsigned)std::min<u64>(gW, 256ull * miPerCu)), dim3(256), 0, d->stream, MA);
                 // the probe scan may run past the last group: empty records behind ALL records
                 u64 mc[3];
@@ -545,7 +547,7 @@ int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t
                 HIPCHK(hipMemsetAsync(krec + mc[0], 0, MI_SCAN_PAD * sizeof(u64), d->stream));   // (mc[0] records, at krec[0 .. mc[0]))
                 lap("group windows"); mem_sample(d);
                 d->n_groups = mc[1];
-                if (getenv("SAGE2OV_VERIFY_MI")) {
+                if (d->opt.get("SAGE2OV_VERIFY_MI")) {
                     u64* vo = nullptr; HIPCHK(hipMalloc(&vo, 2 * sizeof(u64))); HIPCHK(hipMemsetAsync(vo, 0, 2 * sizeof(u64), d->stream));
                     hipLaunchKernelGGL(k_mi_verify, dim3(grid_for(4 * N, 256)), dim3(256), 0, d->stream, d->readsLoc, N, d->S, d->h, d->seed, d->slots, d->T, mi1, TL, krec, vo);
                     u64 hv2[2]; HIPCHK(hipMemcpyAsync(hv2, vo, sizeof hv2, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream)); hipFree(vo);
@@ -612,7 +614,7 @@ static int build_locality_order(Device* d, u64 lo, u64 hi, const u32** order_out
     // their reads and break each other's runs of shifted reads (window reuse, 5.2) -- hash bits -> probe pass at configs[2]: 18 -> 97.2 ms, 24 -> 78.8, 27 -> 62.5,
     // 30 -> 57.2, 32 -> 56.5, for 0.3 ms more of index build.
     int lg = 32;
-    if (const char* ev = getenv("SAGE2OV_ORDER_BITS")) lg = std::max(1, std::min(32, atoi(ev)));
+    if (const char* ev = d->opt.get("SAGE2OV_ORDER_BITS")) lg = std::max(1, std::min(32, atoi(ev)));
     const u32 ntiles = (u32)((n + PT_TILE - 1) / PT_TILE);
     PtBufs B; B.W = 3;                                                        // {hash, id, meta}
     { WS(a, u32, WS_MINH, 3 * (n + 4)); B.E[0] = a; } { WS(a, u32, WS_OCUR, 3 * (n + 4)); B.E[1] = a; }
@@ -630,11 +632,11 @@ static int build_locality_order(Device* d, u64 lo, u64 hi, const u32** order_out
 }
 static ProbeArgs base_args(Device* d) {
     ProbeArgs A; memset(&A, 0, sizeof A);
-    A.reads = d->readsLoc; A.idOf = d->idOf; A.statusP = d->statusP; A.meta = getenv("SAGE2OV_NO_WINDOW_REUSE") ? nullptr : d->metaP; A.N = d->N; A.S = d->S; A.k = d->k; A.h = d->h; A.slots = d->slots; A.T = d->T; A.csr = d->csr; A.seed = d->seed;
+    A.reads = d->readsLoc; A.idOf = d->idOf; A.statusP = d->statusP; A.meta = d->opt.get("SAGE2OV_NO_WINDOW_REUSE") ? nullptr : d->metaP; A.N = d->N; A.S = d->S; A.k = d->k; A.h = d->h; A.slots = d->slots; A.T = d->T; A.csr = d->csr; A.seed = d->seed;
     A.right = d->right; A.left = d->left; A.conn = d->conn; A.cflag = d->cflag; A.status = d->status; A.counters = d->d_counters;
     A.mi1 = d->mi1; A.TL = d->TL; A.krec = d->krec; A.uniL = d->uniL;
     A.chunkShift = (u32)FAST_CHUNK_LOG;      // (plan_fast_grid may double the positions per block visit)
-    A.noRun = getenv("SAGE2OV_NO_RUN_MODE") ? 1u : 0u;
+    A.noRun = d->opt.get("SAGE2OV_NO_RUN_MODE") ? 1u : 0u;
     return A;
 }
 
@@ -683,18 +685,18 @@ static bool launch_fast_any(Device* d, ProbeArgs& A, unsigned blocks) {
 // SAGE2OV_FAST_BLOCKS_PER_CU=<n>: one uniform phase of n blocks per CU (diagnostic).
 // SAGE2OV_FAST_BLOCKS_PER_CU=<n>: one uniform phase of n blocks per CU (diagnostic); SAGE2OV_TEST_PHASE_BLOCKS=<b>: phases of b blocks instead of 4096 (tests: several
 // phases on a few thousand reads).
-static unsigned plan_fast_grid(ProbeArgs& A, u64 n, bool writesHits = false) {
-    const char* eu = getenv("SAGE2OV_FAST_BLOCKS_PER_CU"); const int uniform = eu ? std::max(1, atoi(eu)) : 0;
-    const char* ep = getenv("SAGE2OV_TEST_PHASE_BLOCKS"); const u64 PB = ep ? (u64)std::max(1, atoi(ep)) : 4096;
+static unsigned plan_fast_grid(const Options& O, ProbeArgs& A, u64 n, bool writesHits = false) {
+    const char* eu = O.get("SAGE2OV_FAST_BLOCKS_PER_CU"); const int uniform = eu ? std::max(1, atoi(eu)) : 0;
+    const char* ep = O.get("SAGE2OV_TEST_PHASE_BLOCKS"); const u64 PB = ep ? (u64)std::max(1, atoi(ep)) : 4096;
     memset(A.phase, 0, sizeof A.phase);
     // positions per block visit: twice FAST_CHUNK for launches big enough that the coarser grid does not show (kernels_probe_fast.inc: 24 M positions and more;
     // SAGE2OV_FAST_CHUNK_SHIFT = 7 / 8 overrides); launches that write hits out keep the small size
     u32 cs = (u32)FAST_CHUNK_LOG + ((n >= 24000000ull && !writesHits) ? 1u : 0u);
-    if (const char* ec = getenv("SAGE2OV_FAST_CHUNK_SHIFT")) cs = (u32)std::max(FAST_CHUNK_LOG, std::min(FAST_CHUNK_LOG + 3, atoi(ec)));
+    if (const char* ec = O.get("SAGE2OV_FAST_CHUNK_SHIFT")) cs = (u32)std::max(FAST_CHUNK_LOG, std::min(FAST_CHUNK_LOG + 3, atoi(ec)));
     A.chunkShift = cs;
     const u64 CH = 1ull << cs, C = (n + CH - 1) / CH;
     if (writesHits || uniform || C <= PB * 8) {
-        const char* eh = getenv("SAGE2OV_FAST_HITS_BLOCKS_PER_CU"); const int hitsPerCu = eh ? std::max(1, atoi(eh)) : 16;
+        const char* eh = O.get("SAGE2OV_FAST_HITS_BLOCKS_PER_CU"); const int hitsPerCu = eh ? std::max(1, atoi(eh)) : 16;
         const u64 nb = std::max<u64>(1, std::min<u64>(C, 256ull * (writesHits ? hitsPerCu : (uniform ? uniform : 16))));
         A.phase[0][0] = 0; A.phase[0][1] = (u32)nb; A.phase[0][2] = (u32)((C + nb - 1) / nb); A.phase[0][3] = 0;
         return (unsigned)nb;
@@ -725,7 +727,7 @@ int dev_probe(Device* d, uint64_t lo, uint64_t hi, std::string& err) {
     ProbeArgs A = base_args(d); A.lo = lo; A.hi = hi;
     const u64 nreads = hi > lo ? hi - lo : 0;
     d->pre.valid = false;
-    const bool seq_only = getenv("SAGE2OV_SEQUENTIAL_PROBE") != nullptr;
+    const bool seq_only = d->opt.get("SAGE2OV_SEQUENTIAL_PROBE") != nullptr;
     if (nreads && !seq_only) {
         WS(slow, u32, WS_SLOW, nreads);
         A.slow = slow; A.slow_cap = nreads;
@@ -739,16 +741,16 @@ int dev_probe(Device* d, uint64_t lo, uint64_t hi, std::string& err) {
         // data a read in a thousand needs it.  So the first 1/128 of the range runs without it (TAIL = 0: such reads are listed), the share of
         // listed reads decides for the rest, and the listed reads go through the TAIL = 1 kernel as an id list afterwards; what that one
         // cannot settle either (more than 128 candidates, overhangs beyond its rows) ends in the sequential kernel, as before.
-        const char* evs = getenv("SAGE2OV_PROBE_SAMPLE_MIN");                 // tests: sample on small inputs too
+        const char* evs = d->opt.get("SAGE2OV_PROBE_SAMPLE_MIN");                 // tests: sample on small inputs too
         const u64 sampleMin = evs ? strtoull(evs, nullptr, 10) : (128u << 10);
-        const char* evt = getenv("SAGE2OV_PROBE_TAIL");                       // "0" / "1" / "2": no sampling, that kernel for everything
+        const char* evt = d->opt.get("SAGE2OV_PROBE_TAIL");                       // "0" / "1" / "2": no sampling, that kernel for everything
         u64 nsample = (nreads >= 4 * sampleMin && !evt) ? std::max<u64>(nreads / 128, sampleMin) : 0;   // (on noisy data the sample is work done twice)
         nsample = (nsample + 2 * FAST_CHUNK - 1) / (2 * FAST_CHUNK) * (2 * FAST_CHUNK);
         int tailKernel = evt ? atoi(evt) : 1; bool anyListed = evt && tailKernel == 0;       // 0 / 1 / 2: see k_probe_fast
         bool launched = true, mainWide = false;
         u64 nslow = 0, ncap = 0; float kms = 0;
         // the clean-data launches of one-length read sets run the sequential-groups form (eight waves per SIMD: -2.4 % at configs[2]); SAGE2OV_PROBE_SEQ=0: the standard form
-        const bool seqForm = !(getenv("SAGE2OV_PROBE_SEQ") && atoi(getenv("SAGE2OV_PROBE_SEQ")) == 0);
+        const bool seqForm = !(d->opt.get("SAGE2OV_PROBE_SEQ") && atoi(d->opt.get("SAGE2OV_PROBE_SEQ")) == 0);
         auto timed = [&](auto&& launch) -> int {                              // one launch of the fast kernel between two events
             HIPCHK(hipEventRecord(d->ev[2], d->stream));
             launch();
@@ -757,14 +759,14 @@ int dev_probe(Device* d, uint64_t lo, uint64_t hi, std::string& err) {
             u64 c2_[2] = {0, 0}; HIPCHK(hipMemcpyAsync(c2_, d->d_counters + 6, sizeof c2_, hipMemcpyDeviceToHost, d->stream));
             HIPCHK(hipStreamSynchronize(d->stream)); nslow = c2_[0]; ncap = c2_[1];
             float ms = 0; hipEventElapsedTime(&ms, d->ev[2], d->ev[3]); kms += ms; d->tm.probe_fast_launches++;
-            if (getenv("SAGE2OV_TIMING")) fprintf(stderr, "[probe] fast kernel launch %.3f ms, listed so far %llu\n", ms, (unsigned long long)nslow);
+            if (d->opt.get("SAGE2OV_TIMING")) fprintf(stderr, "[probe] fast kernel launch %.3f ms, listed so far %llu\n", ms, (unsigned long long)nslow);
             return 0;
         };
         // noisy data, and this context probes every read: the hits of the unresolved reads ARE the verified hits of this pass -- written out
         // now (k_probe_fast<..., 2> with hitBase), filtered by the final statuses in the reduce phase (k_hits_filter)
         auto arm_prehits = [&](ProbeArgs& P, u64 nr, unsigned nb, bool& armed) -> int {
             armed = false;
-            if (!(tailKernel == 2 && d->probeShare == 1.0 && lo == 1 && hi == N + 1 && !getenv("SAGE2OV_NO_PREHITS"))) return 0;
+            if (!(tailKernel == 2 && d->probeShare == 1.0 && lo == 1 && hi == N + 1 && !d->opt.get("SAGE2OV_NO_PREHITS"))) return 0;
             const u64 hcap = nr * 72 + (u64)nb * SAGE2OV_FAST_WPB * HITS_CHUNK;
             Hit* hb = (Hit*)ws_get(d, WS_HITS, hcap * sizeof(Hit));                  // (72 hits per read: 49 GB at 42 M reads -- no room: the reduce phase makes its own lists)
             if (!hb) { (void)hipGetLastError(); return 0; }
@@ -782,21 +784,21 @@ int dev_probe(Device* d, uint64_t lo, uint64_t hi, std::string& err) {
         };
         if (nsample && nsample < nreads) {
             ProbeArgs As = A; As.hi = lo + nsample;
-            int rc = timed([&] { const unsigned nbs = plan_fast_grid(As, nsample); launched = (seqForm && launch_fast_seq_any(d, As, nbs, 2)) || launch_fast_any<0, 0>(d, As, nbs); }); if (rc) return rc;
+            int rc = timed([&] { const unsigned nbs = plan_fast_grid(d->opt, As, nsample); launched = (seqForm && launch_fast_seq_any(d, As, nbs, 2)) || launch_fast_any<0, 0>(d, As, nbs); }); if (rc) return rc;
             if (launched) {
                 anyListed = true;
                 // listed for being inconsistent: more than half -> state machine for every read; more than 3 % -> kernel that carries it.  Listed for having more candidates
                 // than slots (high coverage), more than 3 %: the rest runs the WIDE form (256 slots) right away instead of listing a fifth of the reads again
                 const u64 nInc = nslow - std::min(nslow, ncap);
                 tailKernel = nInc * 2 > nsample ? 2 : (nInc * 32 > nsample ? 1 : 0);
-                mainWide = tailKernel == 0 && ncap * 32 > nsample && d->uniL != 0 && !getenv("SAGE2OV_NO_WIDE");
-                ProbeArgs Ar = A; Ar.lo = lo + nsample; const unsigned nb = plan_fast_grid(Ar, nreads - nsample, tailKernel == 2);
+                mainWide = tailKernel == 0 && ncap * 32 > nsample && d->uniL != 0 && !d->opt.get("SAGE2OV_NO_WIDE");
+                ProbeArgs Ar = A; Ar.lo = lo + nsample; const unsigned nb = plan_fast_grid(d->opt, Ar, nreads - nsample, tailKernel == 2);
                 bool armed = false; { int rca = arm_prehits(Ar, nreads - nsample, nb, armed); if (rca) return rca; }
                 rc = timed([&] { if (tailKernel == 2) launch_fast_any<0, 2>(d, Ar, nb); else if (tailKernel == 1) launch_fast_any<0, 1>(d, Ar, nb); else if (!((mainWide && launch_fast_seq_any(d, Ar, nb, 4)) || (seqForm && launch_fast_seq_any(d, Ar, nb, 2)))) launch_fast_any<0, 0>(d, Ar, nb); }); if (rc) return rc;
                 if (armed) { int rca = close_prehits(); if (rca) return rca; }
             }
         } else {
-            ProbeArgs Aw = A; const unsigned nb = plan_fast_grid(Aw, nreads, tailKernel == 2); bool armed = false; { int rca = arm_prehits(Aw, nreads, nb, armed); if (rca) return rca; }
+            ProbeArgs Aw = A; const unsigned nb = plan_fast_grid(d->opt, Aw, nreads, tailKernel == 2); bool armed = false; { int rca = arm_prehits(Aw, nreads, nb, armed); if (rca) return rca; }
             int rc = timed([&] { launched = tailKernel == 2 ? launch_fast_any<0, 2>(d, Aw, nb) : (tailKernel == 1 ? launch_fast_any<0, 1>(d, Aw, nb) : ((seqForm && launch_fast_seq_any(d, Aw, nb, 2)) || launch_fast_any<0, 0>(d, Aw, nb))); }); if (rc) return rc;
             if (armed && launched) { int rca = close_prehits(); if (rca) return rca; }
         }
@@ -809,12 +811,12 @@ int dev_probe(Device* d, uint64_t lo, uint64_t hi, std::string& err) {
         u32* list = slow;
         // Reads the 128-slot forms listed, many of them (high coverage: more than 128 candidates; tests/diag/coverage_sweep.py): first the WIDE sequential-groups form
         // (256 candidate slots, no state machine); what it lists in turn -- inconsistent reads, more than 256 candidates -- goes on as before.
-        const u64 wideMin = getenv("SAGE2OV_PROBE_WIDE_MIN") ? strtoull(getenv("SAGE2OV_PROBE_WIDE_MIN"), nullptr, 10) : 4096;
-        if (launched && anyListed && nslow >= wideMin && tailKernel != 2 && !mainWide && d->uniL && !getenv("SAGE2OV_NO_WIDE")) {
+        const u64 wideMin = d->opt.get("SAGE2OV_PROBE_WIDE_MIN") ? strtoull(d->opt.get("SAGE2OV_PROBE_WIDE_MIN"), nullptr, 10) : 4096;
+        if (launched && anyListed && nslow >= wideMin && tailKernel != 2 && !mainWide && d->uniL && !d->opt.get("SAGE2OV_NO_WIDE")) {
             WS(slow2, u32, WS_SLOW2, nslow);
             HIPCHK(hipMemsetAsync(d->d_counters + 6, 0, 2 * sizeof(u64), d->stream));
             ProbeArgs B = base_args(d); B.ids = slow; B.n_ids = nslow; B.slow = slow2; B.slow_cap = nslow;
-            const u64 nl = nslow; const unsigned nbl = plan_fast_grid(B, nl); bool wide = false;
+            const u64 nl = nslow; const unsigned nbl = plan_fast_grid(d->opt, B, nl); bool wide = false;
             int rc = timed([&] { wide = launch_fast_seq_any(d, B, nbl, 4); }); if (rc) return rc;
             if (wide) {                                                          // (the survivors' list becomes the list: copied back so that the steps below find it where they expect it)
                 if (nslow) HIPCHK(hipMemcpyAsync(slow, slow2, nslow * sizeof(u32), hipMemcpyDeviceToDevice, d->stream));
@@ -828,7 +830,7 @@ int dev_probe(Device* d, uint64_t lo, uint64_t hi, std::string& err) {
             B.stamps = A.stamps;
 #endif
             const u64 nl = nslow;
-            const unsigned nbl = plan_fast_grid(B, nl); int rc = timed([&] { launch_fast_any<0, 1>(d, B, nbl); }); if (rc) return rc;
+            const unsigned nbl = plan_fast_grid(d->opt, B, nl); int rc = timed([&] { launch_fast_any<0, 1>(d, B, nbl); }); if (rc) return rc;
             list = slow2;
         }
         d->tm.probe_kernel_ms += kms; d->tm.probe_launches++;
@@ -1111,7 +1113,7 @@ struct XoAvx2 {
 // rank[] once per list entry -- with positions the ~100 neighbours of a read sit in a handful of cache lines.  `startOrder` lists the
 // positions of the unresolved reads in ASCENDING ID order (the order in which the serial loop starts its searches, :513).
 template <class F>
-static void explore_order_impl(const std::vector<u32>& pos, const std::vector<const u32*>& lists, const std::vector<u32>& lenp, const std::vector<uint8_t>& hasCand,
+static void explore_order_impl(const Options& O, const std::vector<u32>& pos, const std::vector<const u32*>& lists, const std::vector<u32>& lenp, const std::vector<uint8_t>& hasCand,
                                u64 N, const std::vector<u32>& startOrder, std::vector<u32>& rankv) {
     const size_t n = pos.size();
     // per read: where its list is, how long, whether candidates of the reciprocal pass hang on it -- one 16-byte record, one cache line per visit
@@ -1137,21 +1139,21 @@ static void explore_order_impl(const std::vector<u32>& pos, const std::vector<co
     // walk (racy reads of rank[]: only hints) and touches the lists it would scan, so that they are in the shared caches when the walk
     // arrives.  It changes nothing the walk reads; SAGE2OV_WALK_HELPER=0 turns it off.
     std::thread helper; cpu_set_t savedMask; CPU_ZERO(&savedMask); bool pinnedMain = false;
-    { const char* ev = getenv("SAGE2OV_WALK_HELPER"); const bool want = ev ? atoi(ev) != 0 : std::thread::hardware_concurrency() > 1;
+    { const char* ev = O.get("SAGE2OV_WALK_HELPER"); const bool want = ev ? atoi(ev) != 0 : std::thread::hardware_concurrency() > 1;
       if (want) {
         int sib = -1; const int me = sched_getcpu();
         if (me >= 0) { char path[128]; snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", me);
             if (FILE* f = fopen(path, "r")) { int a = -1, b = -1; char sep = 0; if (fscanf(f, "%d%c%d", &a, &sep, &b) >= 3) sib = a == me ? b : a; fclose(f); }
             // measured (EPYC 9575F, 10 M reads): helper on the next core of the same 8-core complex (shared L3) 1.9 s, on the SMT sibling 2.3 s
             // (it shares the walk's issue slots), no helper 3.3 s -- so the neighbour core is tried first
-            if (!getenv("SAGE2OV_WALK_SMT_SIBLING")) { const int nb = (me & ~7) | ((me + 1) & 7); cpu_set_t al; CPU_ZERO(&al); if (sched_getaffinity(0, sizeof al, &al) == 0 && CPU_ISSET(nb, &al)) sib = nb; } }
+            if (!O.get("SAGE2OV_WALK_SMT_SIBLING")) { const int nb = (me & ~7) | ((me + 1) & 7); cpu_set_t al; CPU_ZERO(&al); if (sched_getaffinity(0, sizeof al, &al) == 0 && CPU_ISSET(nb, &al)) sib = nb; } }
         cpu_set_t allowed; CPU_ZERO(&allowed); if (sib >= 0 && (sched_getaffinity(0, sizeof allowed, &allowed) != 0 || !CPU_ISSET(sib, &allowed))) sib = -1;
         // Pinning (this thread to its current core for the duration of the walk, the helper to a neighbour) is what the 1.9 s were measured with, but a library
         // call should not fight over cores with other ranks of the same job: off by default when a launcher started several local ranks
         // (LOCAL_WORLD_SIZE > 1), SAGE2OV_WALK_PIN=0/1 decides otherwise.  Without it the helper still runs, wherever the scheduler puts it.
-        { const char* pe = getenv("SAGE2OV_WALK_PIN"); const char* lw = getenv("LOCAL_WORLD_SIZE"); const bool pin = pe ? atoi(pe) != 0 : !(lw && atoi(lw) > 1); if (!pin) sib = -1; }
+        { const char* pe = O.get("SAGE2OV_WALK_PIN"); const char* lw = O.get("LOCAL_WORLD_SIZE"); const bool pin = pe ? atoi(pe) != 0 : !(lw && atoi(lw) > 1); if (!pin) sib = -1; }
         if (sib >= 0 && pthread_getaffinity_np(pthread_self(), sizeof savedMask, &savedMask) == 0) { cpu_set_t one; CPU_ZERO(&one); CPU_SET(me, &one); pinnedMain = pthread_setaffinity_np(pthread_self(), sizeof one, &one) == 0; }   // (restored when the walk ends)
-        static const int AHEAD = getenv("SAGE2OV_WALK_AHEAD") ? atoi(getenv("SAGE2OV_WALK_AHEAD")) : 4, WINDOW = 24;
+        const int AHEAD = O.get("SAGE2OV_WALK_AHEAD") ? atoi(O.get("SAGE2OV_WALK_AHEAD")) : 4, WINDOW = 24;
         helper = std::thread([&, sib]() {
             if (sib >= 0) { cpu_set_t one; CPU_ZERO(&one); CPU_SET(sib, &one); pthread_setaffinity_np(pthread_self(), sizeof one, &one); }
             size_t done = 0; u32 sink = 0;
@@ -1174,13 +1176,13 @@ static void explore_order_impl(const std::vector<u32>& pos, const std::vector<co
     struct HelperJoin { std::thread& t; std::atomic<bool>& d; cpu_set_t& m; bool& pinned;
                         ~HelperJoin() { d.store(true, std::memory_order_release); if (t.joinable()) t.join(); if (pinned) pthread_setaffinity_np(pthread_self(), sizeof m, &m); } } helperJoin{helper, walkDone, savedMask, pinnedMain};
     u64 tcA = 0, tcB = 0, tcC = 0, tcD = 0;
-    u64 stPops = 0, stMarks = 0, stScanA = 0, stScanB = 0, stAnyFalse = 0, stEvB = 0, stStarts = 0; const bool stats = getenv("SAGE2OV_TIMING") != nullptr;
+    u64 stPops = 0, stMarks = 0, stScanA = 0, stScanB = 0, stAnyFalse = 0, stEvB = 0, stStarts = 0; const bool stats = O.get("SAGE2OV_TIMING") != nullptr;
     auto explore_neighbours = [&](u32 r) {                                       // every still unexplored neighbour this read sees, in list order (:531-541)
         const u32* plist = pl[r].p; const u32 en = pl[r].n; stMarks++; stScanA += en;
         const u64 t0_ = stats ? xo_ticks() : 0;
         for (u32 x = F::next_unexplored(plist, 0, en, rank); x < en; x = F::next_unexplored(plist, x + 1, en, rank)) {
             const u32 to = plist[x] & XO_IDM; __atomic_store_n(&rank[to], ++ctr, __ATOMIC_RELAXED); queue.push_back(to);
-            static const int PFE = getenv("SAGE2OV_WALK_PFE") ? atoi(getenv("SAGE2OV_WALK_PFE")) : 1;
+            const int PFE = O.get("SAGE2OV_WALK_PFE") ? atoi(O.get("SAGE2OV_WALK_PFE")) : 1;
             if (PFE) { const PL& t = pl[to]; if (t.p) { __builtin_prefetch(t.p); __builtin_prefetch(t.p + 16); __builtin_prefetch(t.p + 32); __builtin_prefetch(t.p + 48); } }   // it is marked (its list scanned) within a few pops
         }
         if (stats) tcA += xo_ticks() - t0_;
@@ -1222,12 +1224,12 @@ static void explore_order_impl(const std::vector<u32>& pos, const std::vector<co
 // kind matter.  Exact (0 of 8.7 M ranks differ on the 10 M-read repeat data set) and 1.28 -> 0.9-1.0 s for the walk itself, but the segments take 115 ms to build on 16
 // host threads and the reduce phase as a whole came out level (1.80-1.84 s against 1.81-1.99 s): the walk is a chain of ~1 event per pop with ~100 cycles of scattered work
 // each, not a scan-bound loop.  DESIGN 5.5.)
-static void explore_order(const std::vector<u32>& pos, const std::vector<const u32*>& lists, const std::vector<u32>& lenp, const std::vector<uint8_t>& hasCand,
+static void explore_order(const Options& O, const std::vector<u32>& pos, const std::vector<const u32*>& lists, const std::vector<u32>& lenp, const std::vector<uint8_t>& hasCand,
                           u64 N, const std::vector<u32>& startOrder, std::vector<u32>& rank) {
 #if defined(__x86_64__)
-    if (__builtin_cpu_supports("avx2") && !getenv("SAGE2OV_WALK_SCALAR")) { explore_order_impl<XoAvx2>(pos, lists, lenp, hasCand, N, startOrder, rank); return; }
+    if (__builtin_cpu_supports("avx2") && !O.get("SAGE2OV_WALK_SCALAR")) { explore_order_impl<XoAvx2>(O, pos, lists, lenp, hasCand, N, startOrder, rank); return; }
 #endif
-    explore_order_impl<XoScalar>(pos, lists, lenp, hasCand, N, startOrder, rank);
+    explore_order_impl<XoScalar>(O, pos, lists, lenp, hasCand, N, startOrder, rank);
 }
 
 // Multi-rank contexts (shareRank / shareWorld): hit lists, adjacency and -- with long buckets -- the exploration order are computed for ALL unresolved
@@ -1257,7 +1259,7 @@ int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved
     if (nun == 0) { *done = 1; return 0; }
     if (nun < min_unresolved) return 0;
     const bool ranked = d->n_long != 0;                                          // one-sided discovery: the exploration order decides which edges exist
-    const bool timing = getenv("SAGE2OV_TIMING") != nullptr; auto tp = std::chrono::steady_clock::now();
+    const bool timing = d->opt.get("SAGE2OV_TIMING") != nullptr; auto tp = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) { if (!timing) return; hipStreamSynchronize(d->stream); auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[reduce/device] %-30s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(t - tp).count()); tp = t; };
     // directional hits of the unresolved reads, device resident: the fast kernel in its hit-list form (locality order, minimiser
     // groups), the sequential kernel for the few reads it hands over (> 128 candidates, ambiguous tags) and for the 16-word layout
@@ -1279,11 +1281,11 @@ int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved
         WS(slow, u32, WS_SLOW, N + 1);
         const unsigned blocks = (unsigned)std::min<u64>((N + FAST_CHUNK - 1) / FAST_CHUNK, 256ull * 16);
         u64 cap = std::max<u64>(1 << 16, nun * 80) + (u64)blocks * SAGE2OV_FAST_WPB * HITS_CHUNK; bool ok = false;
-        if (getenv("SAGE2OV_TEST_SMALL_BUFFERS")) cap = 8192;                      // tests: start far too small, the sizing loop must recover
+        if (d->opt.get("SAGE2OV_TEST_SMALL_BUFFERS")) cap = 8192;                      // tests: start far too small, the sizing loop must recover
         // The initial pass may have written every read's hits out already (dev_probe, noisy data): drop the ones with a resolved end, in place, and
         // run the hit-list kernel only for the unresolved reads that pass did not cover (its sample, hand-overs).  Any shortage of room: the
         // ordinary way below, from scratch.
-        if (d->pre.valid && !getenv("SAGE2OV_TEST_SMALL_BUFFERS")) {
+        if (d->pre.valid && !d->opt.get("SAGE2OV_TEST_SMALL_BUFFERS")) {
             d->pre.valid = false;                                                     // (consumed: the filter works in place)
             dh = d->pre.hits; const u64 pcap = d->pre.cap; u64 used = d->pre.used;
             WS(noneList, u32, WS_PRE_NONE, N + 2);
@@ -1295,7 +1297,7 @@ int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved
             if (fc[1]) {                                                              // unresolved reads without written hits: the hit-list kernel over their positions, appending
                 u64 c3[3] = {used, 0, 0}; HIPCHK(hipMemcpyAsync(d->d_counters + 4, c3, sizeof c3, hipMemcpyHostToDevice, d->stream));
                 ProbeArgs A = base_args(d); A.ids = noneList; A.n_ids = fc[1]; A.hits = dh; A.hits_cap = pcap; A.hitcount = hitcount; A.slow = slow; A.slow_cap = N + 1;
-                if (launch_fast_any<1, 0>(d, A, plan_fast_grid(A, fc[1], true))) {
+                if (launch_fast_any<1, 0>(d, A, plan_fast_grid(d->opt, A, fc[1], true))) {
                     HIPCHK(hipGetLastError());
                     HIPCHK(hipMemcpyAsync(c3, d->d_counters + 4, sizeof c3, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
                     if (c3[0] > pcap) ok = false;
@@ -1337,11 +1339,11 @@ int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved
     }
     *n_hits = nh;
     lap("hit lists");
-    if (getenv("SAGE2OV_DEBUG_HITS") && nslots) {                                    // diagnostic: an order-independent checksum of the hit lists
+    if (d->opt.get("SAGE2OV_DEBUG_HITS") && nslots) {                                    // diagnostic: an order-independent checksum of the hit lists
         std::vector<Hit> hh(nslots); HIPCHK(hipMemcpy(hh.data(), dh, nslots * sizeof(Hit), hipMemcpyDeviceToHost));
         u64 sum = 0, cnt = 0, sumseq = 0, sumF = 0, cntF = 0; u64 idx = 0;
         for (const Hit& h : hh) { const bool fastPart = idx++ < dbgFastEnd; if (h.from) { u64 x = ((u64)h.from << 32) ^ ((u64)h.to * 0x9E3779B97F4A7C15ull) ^ ((u64)(u32)h.len << 8) ^ h.type; x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; sum += x; sumseq += h.seq; cnt++; if (fastPart) { sumF += x; cntF++; } } }
-        if (const char* path = getenv("SAGE2OV_DEBUG_HITS_FILE")) { FILE* f = fopen(path, "wb"); if (f) { fwrite(hh.data(), sizeof(Hit), (size_t)std::min<u64>(dbgFastEnd, nslots), f); fclose(f); } }
+        if (const char* path = d->opt.get("SAGE2OV_DEBUG_HITS_FILE")) { FILE* f = fopen(path, "wb"); if (f) { fwrite(hh.data(), sizeof(Hit), (size_t)std::min<u64>(dbgFastEnd, nslots), f); fclose(f); } }
         fprintf(stderr, "[reduce/device] hits %llu in %llu slots, checksum %016llx, seq sum %llu, nh %llu; fast kernel's part: %llu hits, checksum %016llx\n", (unsigned long long)cnt, (unsigned long long)nslots, (unsigned long long)sum, (unsigned long long)sumseq, (unsigned long long)nh, (unsigned long long)cntF, (unsigned long long)sumF);
     }
     const u64 nc = d->n_cand;
@@ -1371,7 +1373,7 @@ int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved
         if (!d->rrStaging) d->rrStaging = new RrStaging();
         RrStaging& staging = *(RrStaging*)d->rrStaging; staging.next = 0;
         std::vector<std::vector<u32>> heavyLists;                                 // lists beyond the device sort (reads that thousands of others see): sorted and merged on the host
-        u64 sliceEntries = 1ull << 30; if (const char* ev = getenv("SAGE2OV_TEST_RANK_SLICE")) sliceEntries = std::max<u64>(1024, strtoull(ev, nullptr, 10));
+        u64 sliceEntries = 1ull << 30; if (const char* ev = d->opt.get("SAGE2OV_TEST_RANK_SLICE")) sliceEntries = std::max<u64>(1024, strtoull(ev, nullptr, 10));
         WS(lenp, u32, WS_RR_LEN, nun + 2);
         for (u64 w0 = 0; w0 < nun;) {
             u64 w1 = w0, tot0 = 0; while (w1 < nun && (w1 == w0 || tot0 + hDegp[w1] <= sliceEntries)) tot0 += hDegp[w1++];
@@ -1427,7 +1429,7 @@ int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved
             HIPCHK(hipMemcpyAsync(startOrder.data(), sout, nun * sizeof(u32), hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
         }
         lap("walk set-up (device + download)");
-        explore_order(posOf, listPtr, hLen, hasCand, N, startOrder, rankByPos);
+        explore_order(d->opt, posOf, listPtr, hLen, hasCand, N, startOrder, rankByPos);
         if (rankByPos.size() != N + 2) { err = "exploration walk: table allocation failed"; return SAGE2OV_ERR_NOMEM; }
         lap("exploration order (host)");
         { WS(rk, u32, WS_RR_RANK, N + 2); rankDev = rk; }
@@ -1451,7 +1453,7 @@ int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved
     const u32* const idsAll = ids; ids = ids + wlo; const u64 nunAll = nun; nun = whi - wlo; (void)idsAll; (void)nunAll;
     WS(svn, u32, WS_NEED, nun + 2); WS(svoff, u32, WS_OWNER, nun + 2);
     // (the marks' grid: a wave per read, blocks walk the list round-robin; blocks per CU -> reduce phase at configs[1] + 0.1 % errors: 16 -> 69.5 ms, 64 -> 66.0, 256 -> 65.2, 1024 -> 65.2: the tail again)
-    static const u64 raPerCu = getenv("SAGE2OV_RA_GRID_PER_CU") ? std::max(1, atoi(getenv("SAGE2OV_RA_GRID_PER_CU"))) : 256;
+    const u64 raPerCu = d->opt.get("SAGE2OV_RA_GRID_PER_CU") ? std::max(1, atoi(d->opt.get("SAGE2OV_RA_GRID_PER_CU"))) : 256;
     const unsigned gb = (unsigned)std::max<u64>(1, std::min<u64>((nun + 3) / 4, 256ull * raPerCu));
     const u64 heavyCap = 1 << 16; WS(heavy, u32, WS_RA_HEAVY, heavyCap);
     WS(ent32, u32, WS_RA_ENT32, tot + 64); WS(split, u32, WS_RA_SPLIT, N + 2);
@@ -1481,7 +1483,7 @@ int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved
         HIPCHK(hipMemcpy(c, d->d_counters + 8, sizeof c, hipMemcpyDeviceToHost));
     }
     u64 nsv = 0; if (nun) { int rc = scan_u32(d, svn, nun, svoff, &nsv, err); if (rc) return rc; }
-    if (d->n_cand + nsv > d->cand_cap || getenv("SAGE2OV_TEST_SMALL_BUFFERS")) {
+    if (d->n_cand + nsv > d->cand_cap || d->opt.get("SAGE2OV_TEST_SMALL_BUFFERS")) {
         EdgeCand* ncand = nullptr; const u64 ncap = d->n_cand + nsv + 1024;
         HIPCHK(hipMalloc(&ncand, ncap * sizeof(EdgeCand)));
         HIPCHK(hipMemcpyAsync(ncand, d->cand, d->n_cand * sizeof(EdgeCand), hipMemcpyDeviceToDevice, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
@@ -1507,7 +1509,7 @@ int dev_collect_reduce_edges(Device* d, const std::vector<uint32_t>& unresolved,
     out.clear(); const u64 n = d->n_cand; if (n == 0) return 0;
     EdgeCand* buf = nullptr; u64 cap = 1 << 16;
     const u32 nUn = (u32)std::min<size_t>(unresolved.size(), 1u << 30);
-    if (nUn && nUn <= FEW_MAX / 3 && !getenv("SAGE2OV_TEST_GENERAL_COLLECT")) {
+    if (nUn && nUn <= FEW_MAX / 3 && !d->opt.get("SAGE2OV_TEST_GENERAL_COLLECT")) {
         // a handful of unresolved reads (see k_red_collect_few): the short list = these reads + their two extension partners, found from their records
         WS(dIds, u32, WS_IDS, 4 * (u64)FEW_MAX); WS(dRec, u64, WS_NEED, 2 * (u64)nUn + 2);
         u32* dNeed = dIds + FEW_MAX;
@@ -1564,7 +1566,7 @@ int dev_meminfo(Device* d, uint64_t* out4, std::string& err) {
     HIPCHK(hipSetDevice(d->ordinal));
     size_t fr = 0, to = 0; HIPCHK(hipMemGetInfo(&fr, &to)); mem_sample(d);
     u64 arena = 0; for (auto& b : d->ws) arena += b.cap;
-    if (getenv("SAGE2OV_MEMINFO")) {                                         // diagnostic: the big buffers of the arena, by workspace id (enum order)
+    if (d->opt.get("SAGE2OV_MEMINFO")) {                                         // diagnostic: the big buffers of the arena, by workspace id (enum order)
         fprintf(stderr, "[meminfo] free %.2f GB of %.2f, lowest %.2f, arena %.2f GB, N %llu, diet %d:", fr / 1e9, to / 1e9, d->memLow / 1e9, arena / 1e9, (unsigned long long)d->N, (int)d->diet);
         for (int x = 0; x < WS_COUNT; x++) if (d->ws[x].cap >= (64u << 20)) fprintf(stderr, " ws%d=%.2f", x, d->ws[x].cap / 1e9);
         fprintf(stderr, "\n");
@@ -1720,7 +1722,7 @@ void dev_simplify_release(Device* d) { if (d->s4keep) { hipSetDevice(d->ordinal)
 
 int dev_simplify(Device* d, SimplifiedGraph& out, std::string& err) {
     HIPCHK(hipSetDevice(d->ordinal));
-    const bool timing = getenv("SAGE2OV_TIMING") != nullptr; auto tp = std::chrono::steady_clock::now();
+    const bool timing = d->opt.get("SAGE2OV_TIMING") != nullptr; auto tp = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) { if (!timing) return; auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[step 4] %-40s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(t - tp).count()); tp = t; };
     dev_simplify_release(d);
     lap("release of the previous result");
@@ -1767,7 +1769,7 @@ int dev_simplify(Device* d, SimplifiedGraph& out, std::string& err) {
     auto contract = [&](u64* merged) -> int {
         int rc = adjacency(); if (rc) return rc;
         HIPCHK(hipMemsetAsync(forced, 0, N + 2, st));
-        const S4State* fin = nullptr; bool plainJumping = getenv("SAGE2OV_S4_PLAIN_JUMPING") != nullptr;
+        const S4State* fin = nullptr; bool plainJumping = d->opt.get("SAGE2OV_S4_PLAIN_JUMPING") != nullptr;
         for (int round = 0;; round++) {
             if (round > 64) { err = "step 4: chain promotion does not settle"; return SAGE2OV_ERR_INTERNAL; }
             hipLaunchKernelGGL(k_s4_contractible, gN, b256, 0, st, g, N, forced, cont, h0, h1);

@@ -62,16 +62,32 @@ struct AdjEdge { uint32_t to; uint8_t type; uint8_t mark; uint32_t len; };
 
 // SAGE2OV_TIMING: wall-clock laps of the host-side stages (file input, step 1, the writers) on stderr
 struct HostLap {
-    const bool on = getenv("SAGE2OV_TIMING") != nullptr; const char* stage; std::chrono::steady_clock::time_point tp = std::chrono::steady_clock::now();
-    explicit HostLap(const char* s) : stage(s) {}
+    const bool on; const char* stage; std::chrono::steady_clock::time_point tp = std::chrono::steady_clock::now();
+    HostLap(const sage2ov_ctx* c, const char* s);
     void operator()(const char* what) { if (!on) return; auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[%s] %-36s %8.1f ms\n", stage, what, std::chrono::duration<double, std::milli>(t - tp).count()); tp = t; }
 };
 
 }  // namespace
 
+extern char** environ;
+namespace s2 {
+Options Options::from_env() {
+    Options o;
+    for (char** e = environ; e && *e; e++) {
+        const char* v = *e;
+        if (strncmp(v, "SAGE2OV_", 8) != 0 && strncmp(v, "LOCAL_WORLD_SIZE=", 17) != 0) continue;
+        const char* eq = strchr(v, '='); if (!eq) continue;
+        o.kv.emplace_back(std::string(v, eq - v), std::string(eq + 1));
+    }
+    std::sort(o.kv.begin(), o.kv.end());
+    return o;
+}
+}  // namespace s2
+
 struct sage2ov_ctx {
     sage2ov_config cfg{};
     std::string err;
+    s2::Options opt = s2::Options::from_env();         // the SAGE2OV_* switches as they were when the context was created (sage2ov_options_reload re-reads them)
     // the device: opened by sage2ov_ctx_create, or (SAGE2OV_FLAG_ASYNC_DEVICE) on a helper thread that the first device() call joins
     mutable Device* dev_ = nullptr; mutable std::thread devOpen; mutable std::string devErr;
     bool gpu() const { return cfg.device != SAGE2OV_DEVICE_NONE; }
@@ -98,6 +114,7 @@ struct sage2ov_ctx {
 
     int fail(int code, const std::string& m) { err = m; return code; }
 };
+namespace { HostLap::HostLap(const sage2ov_ctx* c, const char* s) : on(c->opt.flag("SAGE2OV_TIMING")), stage(s) {} }
 
 namespace {
 
@@ -286,7 +303,7 @@ static bool parse_plain_file_parallel(sage2ov_ctx* c, const char* path, std::vec
         }
         return size;
     };
-    const int nt = io_threads(c); HostLap lap("input");
+    const int nt = io_threads(c); HostLap lap(c, "input");
     const size_t nchunks = std::max<size_t>((size_t)nt, std::min<size_t>(4096, size >> 24));
     std::vector<size_t> cut(nchunks + 1); cut[0] = 0; cut[nchunks] = size;
     for (size_t x = 1; x < nchunks; x++) cut[x] = std::max(cut[x - 1], boundary((size * x) / nchunks));
@@ -340,7 +357,7 @@ static bool parse_plain_file_parallel(sage2ov_ctx* c, const char* path, std::vec
 }
 // the threads' pools, one behind the other at the end of the context's staging arrays (each thread copies its own: the arrays are sized without being written)
 static void commit_parts(sage2ov_ctx* c, std::vector<StagePart>& parts) {
-    using Part = StagePart; const int nt = (int)parts.size(); HostLap lap("input");
+    using Part = StagePart; const int nt = (int)parts.size(); HostLap lap(c, "input");
     std::vector<uint64_t> wordBase(nt + 1), readBase(nt + 1); wordBase[0] = c->pool.size(); readBase[0] = c->poolOff.size();
     for (int t = 0; t < nt; t++) { wordBase[t + 1] = wordBase[t] + parts[t].pool.size(); readBase[t + 1] = readBase[t] + parts[t].off.size(); }
     c->pool.resize(wordBase[nt]); c->poolOff.resize(readBase[nt]); c->poolLen.resize(readBase[nt]);
@@ -372,7 +389,7 @@ static bool add_mate_files_parallel(sage2ov_ctx* c, const char* p1, const char* 
 
 // records are split sequentially (cheap: memchr), filtered and packed by all threads in batches
 int add_files(sage2ov_ctx* c, const char* p1, const char* p2) {
-    if (!getenv("SAGE2OV_SEQUENTIAL_READER") && ((p2 && *p2) ? add_mate_files_parallel(c, p1, p2) : add_plain_file_parallel(c, p1))) return SAGE2OV_OK;
+    if (!c->opt.get("SAGE2OV_SEQUENTIAL_READER") && ((p2 && *p2) ? add_mate_files_parallel(c, p1, p2) : add_plain_file_parallel(c, p1))) return SAGE2OV_OK;
     SeqFile f1, f2; if (!f1.open(p1)) return c->fail(SAGE2OV_ERR_IO, std::string("cannot open ") + p1);
     const bool two = p2 && *p2; if (two && !f2.open(p2)) return c->fail(SAGE2OV_ERR_IO, std::string("cannot open ") + p2);
     const int nt = io_threads(c);
@@ -539,7 +556,7 @@ static inline char* put_u(char* p, unsigned long long v) {          // decimal, 
 // all format, barrier, all write -- thread 0 spent 0.26 of 0.46 s working on the 2.8 GB .reads file of 10 M reads).
 template <class F>
 static int write_formatted(sage2ov_ctx* c, FILE* f, uint64_t n, size_t bytes_per_item, F fmt) {
-    const int nt = io_threads(c); HostLap lap("writer");
+    const int nt = io_threads(c); HostLap lap(c, "writer");
     if (fflush(f) != 0) return c->fail(SAGE2OV_ERR_IO, "write failed");
     const off_t pos0 = ftello(f); const int fd = fileno(f);
     // (items of very uneven size -- the edges of P.graph4 carry read lists -- still give every thread several chunks)
@@ -582,18 +599,19 @@ int sage2ov_ctx_create(const sage2ov_config* cfg, sage2ov_ctx** out) {
     if (c->cfg.world == 0) c->cfg.world = 1;
     if (cfg->device != SAGE2OV_DEVICE_NONE) {
         const int ordinal = cfg->device; const double share = 1.0 / (double)c->cfg.world;
-        auto open = [c, ordinal, share] { c->dev_ = dev_create(ordinal, c->devErr); if (c->dev_) dev_set_probe_share(c->dev_, share); };
+        auto open = [c, ordinal, share] { c->dev_ = dev_create(ordinal, c->opt, c->devErr); if (c->dev_) dev_set_probe_share(c->dev_, share); };
         if (cfg->flags & SAGE2OV_FLAG_ASYNC_DEVICE) c->devOpen = std::thread(open);      // the caller stages its input meanwhile; device() joins
         else { open(); if (!c->dev_) { g_create_error = c->devErr; delete c; return SAGE2OV_ERR_DEVICE; } }
     }
     *out = c; return SAGE2OV_OK;
 }
 void sage2ov_ctx_destroy(sage2ov_ctx* c) { if (!c) return; if (Device* d = c->device()) dev_destroy(d); delete c; }
+int sage2ov_options_reload(sage2ov_ctx* c) { if (!c) return SAGE2OV_ERR_ARG; c->opt = s2::Options::from_env(); if (Device* d = c->device()) dev_set_options(d, c->opt); return SAGE2OV_OK; }
 
 int sage2ov_reads_add_ascii(sage2ov_ctx* c, const char* bases, const uint64_t* off, uint64_t n) {
     if (!c || !bases || !off) return SAGE2OV_ERR_ARG;
     if (c->organized) return c->fail(SAGE2OV_ERR_ARG, "reads already organised");
-    if (c->gpu() && !getenv("SAGE2OV_HOST_PACK") && !getenv("SAGE2OV_HOST_ORGANIZE")) {        // staged as they come: the device filters and packs them
+    if (c->gpu() && !c->opt.get("SAGE2OV_HOST_PACK") && !c->opt.get("SAGE2OV_HOST_ORGANIZE")) {        // staged as they come: the device filters and packs them
         if (c->asciiOff.empty()) c->asciiOff.push_back(0);
         const uint64_t base = c->ascii.size(), first = off[0], bytes = off[n] - first;
         c->ascii.insert(c->ascii.end(), bases + first, bases + first + bytes);
@@ -705,13 +723,13 @@ int sage2ov_reads_organize(sage2ov_ctx* c) {                                    
         c->organized = true; c->indexBuilt = c->probed = c->reciprocalDone = c->reduced = c->converted = false;
         return SAGE2OV_OK;
     }
-    const uint64_t n = c->poolLen.size(); HostLap lap("step 1");
+    const uint64_t n = c->poolLen.size(); HostLap lap(c, "step 1");
     int maxL = 0; for (uint64_t i = 0; i < n; i++) maxL = std::max<int>(maxL, c->poolLen[i]);
     c->maxL = maxL; c->S = choose_S(std::max(maxL, 1));
     if (c->S > 32 || maxL > 1018) return c->fail(SAGE2OV_ERR_LIMIT, "reads longer than 1018 bases are not supported");
     if (n >= (1ull << 32)) return c->fail(SAGE2OV_ERR_LIMIT, "too many reads for the host organiser");
     for (uint64_t i = 0; i < n; i++) if (c->poolLen[i] == 0xFFFF) return c->fail(SAGE2OV_ERR_LIMIT, "reads longer than 1018 bases are not supported");
-    if (c->device() && !getenv("SAGE2OV_HOST_ORGANIZE")) {                                 // step 1 on the device: canonical orientation, sort, unique, ids
+    if (c->device() && !c->opt.get("SAGE2OV_HOST_ORGANIZE")) {                                 // step 1 on the device: canonical orientation, sort, unique, ids
         uint64_t N = 0;
         int minL = n ? 0xFFFF : 0; for (uint64_t i = 0; i < n; i++) minL = std::min<int>(minL, c->poolLen[i]);
         lap("length scans");
@@ -878,7 +896,7 @@ static int reads_load_parallel(sage2ov_ctx* c, const char* path) {
 }
 int sage2ov_reads_load(sage2ov_ctx* c, const char* path) {                            // readLoader.cpp:289-307, :38-48
     if (!c || !path) return SAGE2OV_ERR_ARG;
-    if (!getenv("SAGE2OV_SEQUENTIAL_READER")) { const int pr = reads_load_parallel(c, path); if (pr < 0) return pr; if (pr == 1) { c->organized = false; return upload(c); } }
+    if (!c->opt.get("SAGE2OV_SEQUENTIAL_READER")) { const int pr = reads_load_parallel(c, path); if (pr < 0) return pr; if (pr == 1) { c->organized = false; return upload(c); } }
     FILE* f = fopen(path, "r"); if (!f) return c->fail(SAGE2OV_ERR_IO, std::string("cannot open ") + path);
     unsigned long long N = 0; if (fscanf(f, "%llu", &N) != 1) { fclose(f); return c->fail(SAGE2OV_ERR_IO, "bad .reads header"); }
     std::vector<std::string> seqs(N + 1); std::vector<unsigned> fr(N + 1), ln(N + 1); int maxL = 0;
@@ -1079,12 +1097,12 @@ int sage2ov_overlap_reduce(sage2ov_ctx* c) {
     // Many unresolved reads and no long bucket: the order-independent form runs on the device; the serial
     // replay below stays the path for long-bucket indexes (A.7) and for a handful of reads.  Both are exact.
     {
-        const char* ev = getenv("SAGE2OV_DEVICE_REDUCE_MIN");
+        const char* ev = c->opt.get("SAGE2OV_DEVICE_REDUCE_MIN");
         const uint64_t minUn = ev ? strtoull(ev, nullptr, 10) : 4096;
         uint64_t nun0 = 0, nh0 = 0, ins = 0, rem = 0; int done = 0;
         const bool multi = c->cfg.world > 1;
         c->survBase = dev_cand_count(c->device()); c->survCount = 0; c->removedPartial = 0; c->survivorsExchanged = !multi;
-        if (!getenv("SAGE2OV_HOST_REDUCE")) {
+        if (!c->opt.get("SAGE2OV_HOST_REDUCE")) {
             int rc0 = dev_reduce_device(c->device(), minUn, &nun0, &nh0, &ins, &rem, &done, c->err, c->cfg.rank, multi ? c->cfg.world : 1); if (rc0) return rc0;
         }
         if (done) {
@@ -1095,7 +1113,7 @@ int sage2ov_overlap_reduce(sage2ov_ctx* c) {
         }
     }
     std::vector<Hit> hits; uint64_t nun = 0;
-    const bool timing = getenv("SAGE2OV_TIMING") != nullptr; auto tp = std::chrono::steady_clock::now();
+    const bool timing = c->opt.get("SAGE2OV_TIMING") != nullptr; auto tp = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) { if (!timing) return; auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[reduce/host] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(t - tp).count()); tp = t; };
     std::vector<uint32_t> ids;
     int rc = dev_unresolved_hits(c->device(), hits, &nun, c->err, &ids); if (rc) return rc;
@@ -1262,7 +1280,7 @@ static int graph_load_parallel(sage2ov_ctx* c, const char* path, std::vector<sag
 }
 int sage2ov_graph_load(sage2ov_ctx* c, const char* path) {
     if (!c || !path) return SAGE2OV_ERR_ARG;
-    if (!getenv("SAGE2OV_SEQUENTIAL_READER")) {
+    if (!c->opt.get("SAGE2OV_SEQUENTIAL_READER")) {
         std::vector<sage2ov_edge> pe; unsigned long long pnr = 0, pavg = 0;
         if (graph_load_parallel(c, path, pe, pnr, pavg) == 1) { c->goodReads = pnr; c->totalBP = pavg * pnr; return sage2ov_edges_import(c, pe.data(), pe.size()); }
     }
@@ -1327,7 +1345,7 @@ int sage2ov_simplify_stats_get(const sage2ov_ctx* c, sage2ov_simplify_stats* o) 
 int sage2ov_graph4_save(sage2ov_ctx* c, const char* path) {                           // overlapGraph.cpp:338-369, :12-20
     if (!c || !path) return SAGE2OV_ERR_ARG;
     if (!c->g4Valid) return c->fail(SAGE2OV_ERR_ARG, "sage2ov_graph4_save: call sage2ov_graph_simplify first");
-    HostLap lap("graph4");
+    HostLap lap(c, "graph4");
     { int rc = dev_simplify_download(c->device(), c->g4, c->err); if (rc) return rc; }
     lap("download of the simplified graph");
     const SimplifiedGraph& g = c->g4; const uint64_t N = g.N, nh = g.n_half_edges;

@@ -40,10 +40,27 @@ struct FinalEdge { uint32_t from, to, len, len_twin; uint32_t type; };
 
 struct DevTimings { double index_ms = 0, probe_ms = 0, reciprocal_ms = 0, hits_ms = 0, convert_ms = 0, probe_kernel_ms = 0, organize_ms = 0, recip_cond_ms = 0, marks_ms = 0; uint64_t probe_launches = 0, slow_reads = 0, probe_fast_launches = 0; };
 
+// ----------------------------------------------------------------------------------------------
+// Every switch the library takes from the environment (SAGE2OV_*; INTEGRATION.md lists them with their class: T = test-only override of a decision the library
+// otherwise makes by itself -- every route is exact, the tests force each --, G = grid / tuning sweep, D = diagnostic), read ONCE when a context is created:
+// Options::from_env snapshots the SAGE2OV_* variables that are set, the context and its device carry the snapshot, and nothing on the timed path calls getenv
+// (round 3 had ~60 getenv calls, several per step).  sage2ov_options_reload(ctx) takes a new snapshot (tests that change a switch between two steps of one context).
+struct Options {
+    std::vector<std::pair<std::string, std::string>> kv;                 // the variables that are set, sorted by name (a handful at most)
+    static Options from_env();
+    const char* get(const char* name) const {                            // like getenv: the value, or nullptr
+        for (const auto& e : kv) if (e.first == name) return e.second.c_str();
+        return nullptr;
+    }
+    bool flag(const char* name) const { return get(name) != nullptr; }
+    long long num(const char* name, long long dflt) const { const char* v = get(name); return v ? strtoll(v, nullptr, 10) : dflt; }
+};
+
 struct Device;   // opaque, lives in sage2ov_device.hip
 
 // every function returns 0 on success, else a negative SAGE2OV_ERR_* and fills err
-Device* dev_create(int device_ordinal, std::string& err);
+Device* dev_create(int device_ordinal, const Options& opt, std::string& err);
+void dev_set_options(Device* d, const Options& opt);
 void dev_destroy(Device* d);
 void* dev_stream(Device* d);
 
