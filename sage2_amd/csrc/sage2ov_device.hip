@@ -338,7 +338,10 @@ __global__ void k_loc_index(const u32* __restrict__ order, u64 N, u32* idOf, u32
         if (threadIdx.x == 0 && c) atomicAdd(runStarts + ((blockIdx.x >> 3) & 63u), (unsigned long long)c);
     }
     if (p >= N) return;
-    const u32 id = order ? order[3 * p + 1] : (u32)(p + 1); const u32 mt = order ? order[3 * p + 2] : 0xFFFFu;
+    const u32 id = order ? order[3 * p + 1] : (u32)(p + 1); u32 mt = order ? order[3 * p + 2] : 0xFFFFu;
+    // (bit 9, round 4: this read has ANOTHER minimiser hash than the read before it -- nothing of that read's run can be carried over; the fast probe kernel moves the
+    //  boundaries of its waves' visits there)
+    if (order && (p == 0 || order[3 * p] != order[3 * (p - 1)])) mt |= 0x200u;
     idOf[p + 1] = id; posOf[id] = (u32)(p + 1); meta[p + 1] = (unsigned short)mt;       // meta 0xFFFF: no minimiser information (no window reuse)
 }
 __global__ void k_loc_scatter(const u64* __restrict__ reads, const u32* __restrict__ posOf, u64 N, int S, u64* out) {
