@@ -29,6 +29,11 @@ extern "C" {
 #define SAGE2OV_ERR_DEVICE   -3   /* HIP error or no GPU */
 #define SAGE2OV_ERR_NOMEM    -4
 #define SAGE2OV_ERR_LIMIT    -5   /* input exceeds a documented limit */
+/* The documented limits of a context (SAGE2OV_ERR_LIMIT; the reference's widths next to them):
+ *   - read length <= 1018 bases (32 words of 2-bit bases with the 11-bit length field in the last one; inputReader/readLoader.h:28 holds any uint16_t length:
+ *     reads of 1019 .. 65535 bases are refused by the reads_add_* / reads_organize calls, not truncated);
+ *   - fewer than 2^30 unique reads per context (position * 4 + type is a 32-bit entry; economyGraph/hashTable.h:13-18 carries 40-bit ids);
+ *   - at most 2^32 slot pairs of the table (8 slots per read: never reached below the previous limit). */
 #define SAGE2OV_ERR_INTERNAL -6
 
 typedef struct sage2ov_ctx sage2ov_ctx;

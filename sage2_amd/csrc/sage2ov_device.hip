@@ -839,9 +839,9 @@ int dev_probe(Device* d, uint64_t lo, uint64_t hi, std::string& err) {
         d->tm.probe_kernel_ms += kms; d->tm.probe_launches++;
         d->tm.slow_reads += nslow;
 #ifdef SAGE2OV_STAMPS
-        { u64 st[32]; HIPCHK(hipMemcpy(st, d_stamps, sizeof st, hipMemcpyDeviceToHost)); u64 tot = 0; for (int x = 0; x < 24; x++) if (x < 10 || x >= 16) tot += st[x];
+        { u64 st[32]; HIPCHK(hipMemcpy(st, d_stamps, sizeof st, hipMemcpyDeviceToHost)); u64 tot = 0; for (int x = 0; x < 24; x++) if (x < 10 || x >= 14) tot += st[x];
           // stages 0-9 in order of the code; 16 = slot -> window -> entry (before the gathers), 17 = reach, 18 = broadcast of the speculated reads, 19 = compares (8 = what follows them)
-          fprintf(stderr, "[stamps] kernel %.2f ms; share of wave cycles (cycles per read):", kms); for (int x = 0; x < 24; x++) if (x < 10 || x >= 16) fprintf(stderr, " %d:%.1f%% (%.0f)", x, 100.0 * (double)st[x] / (double)tot, st[10] ? (double)st[x] / (double)st[10] : 0.0);
+          fprintf(stderr, "[stamps] kernel %.2f ms; share of wave cycles (cycles per read):", kms); for (int x = 0; x < 24; x++) if (x < 10 || x >= 14) fprintf(stderr, " %d:%.1f%% (%.0f)", x, 100.0 * (double)st[x] / (double)tot, st[10] ? (double)st[x] / (double)st[10] : 0.0);
           fprintf(stderr, "; window reuse: %llu of %llu reads (same minimiser strand as the previous read: %llu), mean shift %.1f\n", (unsigned long long)st[11], (unsigned long long)st[10], (unsigned long long)st[13], st[11] ? (double)st[12] / (double)st[11] : 0.0);
           fprintf(stderr, "[stamps] run mode: %llu reads off the frame, %llu runs ended on a read the general path took; strand changes carried over by mirroring the ring: %llu (refused: %llu -- too far %llu, own entry not in the ring %llu, a window with one read twice %llu), steps: %llu\n", (unsigned long long)st[24], (unsigned long long)st[25], (unsigned long long)st[26], (unsigned long long)st[27], (unsigned long long)st[29], (unsigned long long)st[30], (unsigned long long)st[31], (unsigned long long)st[28]); }
 #endif
