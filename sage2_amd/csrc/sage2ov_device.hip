@@ -1463,13 +1463,15 @@ int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved
     hipLaunchKernelGGL(k_ra_pack32, dim3((unsigned)std::min<u64>((N + 4) / 4, 256ull * 64)), dim3(256), 0, d->stream, ent, offs, deg, (u64)N, ent32, split);
     lap("  final lists filled + 32-bit image");
     HIPCHK(hipEventRecord(d->ev[5], d->stream));                          // (marks_ms: the sharded part of the phase -- marks, removals, re-emission)
+    const u32 noShortcut = d->opt.get("SAGE2OV_RA_NO_SHORTCUT") ? 1u : 0u;      // (tests: the walk of every list, as until round 4)
     if (nun) {
-    hipLaunchKernelGGL((k_ra_mark<128, 8, 0, false>), dim3(gb), dim3(256), 0, d->stream, ids, (u64)nun, offs, deg, ent, ent32, split, rm, svn, d->d_counters + 8, heavy, heavyCap);     // lists of <= 128 entries
-    hipLaunchKernelGGL((k_ra_mark<RA_CAP, 10, 128, true>), dim3(gb), dim3(256), 0, d->stream, ids, (u64)nun, offs, deg, ent, ent32, split, rm, svn, d->d_counters + 8, heavy, heavyCap);   // 129 .. RA_CAP; longer: k_ra_mark_big
+    hipLaunchKernelGGL((k_ra_mark<128, 8, 0, false>), dim3(gb), dim3(256), 0, d->stream, ids, (u64)nun, offs, deg, ent, ent32, split, rm, svn, d->d_counters + 8, heavy, heavyCap, noShortcut);     // lists of <= 128 entries
+    hipLaunchKernelGGL((k_ra_mark<RA_CAP, 10, 128, true>), dim3(gb), dim3(256), 0, d->stream, ids, (u64)nun, offs, deg, ent, ent32, split, rm, svn, d->d_counters + 8, heavy, heavyCap, noShortcut);   // 129 .. RA_CAP; longer: k_ra_mark_big
     }
-    u64 c[2];
+    u64 c[4];
     HIPCHK(hipMemcpyAsync(c, d->d_counters + 8, sizeof c, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
     HIPCHK(hipGetLastError());
+    if (timing) fprintf(stderr, "[reduce/device] marks of %llu of %llu reads by the short cut (k_ra_mark: ra_shortcut), %.2f lists read per read\n", (unsigned long long)c[3], (unsigned long long)nun, nun ? (double)c[2] / (double)nun : 0.0);
     if (c[0] > heavyCap) { if (shareWorld > 1) { err = "reduce: too many oversized lists in this rank's share"; return SAGE2OV_ERR_LIMIT; } return 0; }   // (never seen) that many oversized lists: serial replay (a rank of many cannot decide that alone)
     if (c[0]) {                                                           // lists beyond the LDS kernel: same marking out of global scratch, one wavefront each
         const u32 nhv = (u32)c[0];

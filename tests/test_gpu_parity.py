@@ -39,14 +39,18 @@ def assert_equals_oracle(ctx, o):
     assert np.array_equal(gc, orc) and np.array_equal(gr[1:], orr[1:]) and np.array_equal(gl[1:], orl[1:])
 
 
-@pytest.fixture(params=["default", "device", "host"])
+@pytest.fixture(params=["default", "device", "device_walk", "host"])
 def reduce_path(request, monkeypatch):
     """The reduce phase has two exact implementations (device: order-independent form, taken for many unresolved reads when no
-    bucket is long; host: serial replay).  "device" forces the first wherever its preconditions hold, "host" the second."""
+    bucket is long; host: serial replay).  "device" forces the first wherever its preconditions hold, "host" the second; "device_walk" is the
+    device form with the marks' short cut (kernels_reduce.inc: ra_shortcut) switched off -- every neighbour's list walked, as until round 4."""
     monkeypatch.delenv("SAGE2OV_DEVICE_REDUCE_MIN", raising=False)
     monkeypatch.delenv("SAGE2OV_HOST_REDUCE", raising=False)
-    if request.param == "device":
+    monkeypatch.delenv("SAGE2OV_RA_NO_SHORTCUT", raising=False)
+    if request.param in ("device", "device_walk"):
         monkeypatch.setenv("SAGE2OV_DEVICE_REDUCE_MIN", "1")
+        if request.param == "device_walk":
+            monkeypatch.setenv("SAGE2OV_RA_NO_SHORTCUT", "1")
     elif request.param == "host":
         monkeypatch.setenv("SAGE2OV_HOST_REDUCE", "1")
     return request.param
