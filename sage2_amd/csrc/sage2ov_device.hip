@@ -1445,10 +1445,10 @@ int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved
     lap("  ranks to the device, degrees of the final lists");
     u64 tot = 0; { int rc = scan_u32(d, deg, N + 2, offs, &tot, err); if (rc) return rc; }
     if (tot >= (1ull << 32) - 64) return 0;
-    WS(ent, u64, WS_RA_ENT, tot + 64); WS(rm, uint8_t, WS_RA_RM, tot + 64);
-    if (nc) hipLaunchKernelGGL(k_ra_fill_c, dim3(grid_for(nc, 256)), dim3(256), 0, d->stream, d->cand, (u64)nc, d->reads, d->S, d->uniL, offs, cur, ent);
-    if (ranked) { if (nslots) hipLaunchKernelGGL(k_rr_fill_h, dim3(grid_for(nslots, 256)), dim3(256), 0, d->stream, dh, (u64)nslots, rankDev, d->reads, d->S, d->uniL, offs, cur, ent); }
-    else if (nslots) hipLaunchKernelGGL(k_ra_fill_h, dim3(grid_for(nslots, 256)), dim3(256), 0, d->stream, dh, (u64)nslots, offs, deg, hitcount, ent);
+    WS(ent, u64, WS_RA_ENT, tot + 64); WS(rm, uint8_t, WS_RA_RM, tot + 64); WS(ent32, u32, WS_RA_ENT32, tot + 64);
+    if (nc) hipLaunchKernelGGL(k_ra_fill_c, dim3(grid_for(nc, 256)), dim3(256), 0, d->stream, d->cand, (u64)nc, d->reads, d->S, d->uniL, offs, cur, ent, ent32);
+    if (ranked) { if (nslots) hipLaunchKernelGGL(k_rr_fill_h, dim3(grid_for(nslots, 256)), dim3(256), 0, d->stream, dh, (u64)nslots, rankDev, d->reads, d->S, d->uniL, offs, cur, ent, ent32); }
+    else if (nslots) hipLaunchKernelGGL(k_ra_fill_h, dim3(grid_for(nslots, 256)), dim3(256), 0, d->stream, dh, (u64)nslots, offs, deg, hitcount, ent, ent32);
     if (ranked) { u64 c3[3]; HIPCHK(hipMemcpyAsync(c3, d->d_counters + 8, sizeof c3, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream)); present = c3[2]; }
     HIPCHK(hipMemsetAsync(d->d_counters + 8, 0, 4 * sizeof(u64), d->stream));
     // this rank's share of the unresolved reads: entries [wlo, whi) of the list (any contiguous cut is exact: a read's marks depend on the lists only)
@@ -1459,14 +1459,12 @@ int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved
     const u64 raPerCu = d->opt.get("SAGE2OV_RA_GRID_PER_CU") ? std::max(1, atoi(d->opt.get("SAGE2OV_RA_GRID_PER_CU"))) : 256;
     const unsigned gb = (unsigned)std::max<u64>(1, std::min<u64>((nun + 3) / 4, 256ull * raPerCu));
     const u64 heavyCap = 1 << 16; WS(heavy, u32, WS_RA_HEAVY, heavyCap);
-    WS(ent32, u32, WS_RA_ENT32, tot + 64); WS(split, u32, WS_RA_SPLIT, N + 2);
-    hipLaunchKernelGGL(k_ra_pack32, dim3((unsigned)std::min<u64>((N + 4) / 4, 256ull * 64)), dim3(256), 0, d->stream, ent, offs, deg, (u64)N, ent32, split);
-    lap("  final lists filled + 32-bit image");
+    lap("  final lists filled");
     HIPCHK(hipEventRecord(d->ev[5], d->stream));                          // (marks_ms: the sharded part of the phase -- marks, removals, re-emission)
     const u32 noShortcut = d->opt.get("SAGE2OV_RA_NO_SHORTCUT") ? 1u : 0u;      // (tests: the walk of every list, as until round 4)
     if (nun) {
-    hipLaunchKernelGGL((k_ra_mark<128, 8, 0, false>), dim3(gb), dim3(256), 0, d->stream, ids, (u64)nun, offs, deg, ent, ent32, split, rm, svn, d->d_counters + 8, heavy, heavyCap, noShortcut);     // lists of <= 128 entries
-    hipLaunchKernelGGL((k_ra_mark<RA_CAP, 10, 128, true>), dim3(gb), dim3(256), 0, d->stream, ids, (u64)nun, offs, deg, ent, ent32, split, rm, svn, d->d_counters + 8, heavy, heavyCap, noShortcut);   // 129 .. RA_CAP; longer: k_ra_mark_big
+    hipLaunchKernelGGL((k_ra_mark<128, 8, 0, false>), dim3(gb), dim3(256), 0, d->stream, ids, (u64)nun, offs, deg, ent, ent32, rm, svn, d->d_counters + 8, heavy, heavyCap, noShortcut);     // lists of <= 128 entries
+    hipLaunchKernelGGL((k_ra_mark<RA_CAP, 10, 128, true>), dim3(gb), dim3(256), 0, d->stream, ids, (u64)nun, offs, deg, ent, ent32, rm, svn, d->d_counters + 8, heavy, heavyCap, noShortcut);   // 129 .. RA_CAP; longer: k_ra_mark_big
     }
     u64 c[4];
     HIPCHK(hipMemcpyAsync(c, d->d_counters + 8, sizeof c, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
