@@ -1450,7 +1450,7 @@ int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved
     if (ranked) { if (nslots) hipLaunchKernelGGL(k_rr_fill_h, dim3(grid_for(nslots, 256)), dim3(256), 0, d->stream, dh, (u64)nslots, rankDev, d->reads, d->S, d->uniL, offs, cur, ent, ent32); }
     else if (nslots) hipLaunchKernelGGL(k_ra_fill_h, dim3(grid_for(nslots, 256)), dim3(256), 0, d->stream, dh, (u64)nslots, offs, deg, hitcount, ent, ent32);
     if (ranked) { u64 c3[3]; HIPCHK(hipMemcpyAsync(c3, d->d_counters + 8, sizeof c3, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream)); present = c3[2]; }
-    HIPCHK(hipMemsetAsync(d->d_counters + 8, 0, 4 * sizeof(u64), d->stream));
+    HIPCHK(hipMemsetAsync(d->d_counters + 8, 0, 5 * sizeof(u64), d->stream));
     // this rank's share of the unresolved reads: entries [wlo, whi) of the list (any contiguous cut is exact: a read's marks depend on the lists only)
     const u64 wlo = shareWorld > 1 ? nun * shareRank / shareWorld : 0, whi = shareWorld > 1 ? nun * (shareRank + 1) / shareWorld : nun;
     const u32* const idsAll = ids; ids = ids + wlo; const u64 nunAll = nun; nun = whi - wlo; (void)idsAll; (void)nunAll;
@@ -1462,9 +1462,10 @@ int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved
     lap("  final lists filled");
     HIPCHK(hipEventRecord(d->ev[5], d->stream));                          // (marks_ms: the sharded part of the phase -- marks, removals, re-emission)
     const u32 noShortcut = d->opt.get("SAGE2OV_RA_NO_SHORTCUT") ? 1u : 0u;      // (tests: the walk of every list, as until round 4)
+    WS(mid, u32, WS_RA_SPLIT, nun + 2);                                          // the reads with more than 128 entries, listed by the first launch for the second
     if (nun) {
-    hipLaunchKernelGGL((k_ra_mark<128, 8, 0, false>), dim3(gb), dim3(256), 0, d->stream, ids, (u64)nun, offs, deg, ent, ent32, rm, svn, d->d_counters + 8, heavy, heavyCap, noShortcut);     // lists of <= 128 entries
-    hipLaunchKernelGGL((k_ra_mark<RA_CAP, 10, 128, true>), dim3(gb), dim3(256), 0, d->stream, ids, (u64)nun, offs, deg, ent, ent32, rm, svn, d->d_counters + 8, heavy, heavyCap, noShortcut);   // 129 .. RA_CAP; longer: k_ra_mark_big
+    hipLaunchKernelGGL((k_ra_mark<128, 8, 0, false>), dim3(gb), dim3(256), 0, d->stream, ids, (u64)nun, offs, deg, ent, ent32, rm, svn, d->d_counters + 8, heavy, heavyCap, noShortcut, mid);     // lists of <= 128 entries
+    hipLaunchKernelGGL((k_ra_mark<RA_CAP, 10, 128, true>), dim3(gb), dim3(256), 0, d->stream, ids, (u64)nun, offs, deg, ent, ent32, rm, svn, d->d_counters + 8, heavy, heavyCap, noShortcut, mid);   // 129 .. RA_CAP (the reads the first launch listed); longer: k_ra_mark_big
     }
     u64 c[4];
     HIPCHK(hipMemcpyAsync(c, d->d_counters + 8, sizeof c, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
