@@ -80,12 +80,29 @@ struct Device {
     std::vector<std::pair<void*, size_t>> s4cache;
     void* rrStaging = nullptr;   // ranked reduce: the pinned 2 MB-page host buffers the potential lists are downloaded into, kept from step to step (RrStaging)
     // workspace arena: buffers of the timed path are allocated once and only ever grow (no hipMalloc/hipFree per step)
-    struct Buf { void* p = nullptr; size_t cap = 0; };
+    struct Buf { void* p = nullptr; size_t cap = 0; u32 epoch = 0; };
     Buf ws[WS_COUNT];
+    // MEMORY-DIET MODE (read sets that fill the HBM): the index build's sort buffers and the results of a step (records, candidates, final edges, convert's sort buffers)
+    // take turns with the memory.  Until round 4 each side was hipFree'd when the other one came and hipMalloc'ed again a step later -- 3.4 of the 3.7 s of an index build
+    // at 1.02 G reads, and erratic (tools/ubench/mempool.hip: the same 80 GB come back in 0.5 ms or in 5 s depending on their shape).  Now both sides are CARVED out of one
+    // block that stays: phase A = the index build, phase B = everything from the probe pass to the next build; a phase starts with an empty block (ph_begin: the callers
+    // have synchronised the stream, as they did in front of hipFree).  The first step sizes the block (what does not fit yet gets blocks of its own for that phase);
+    // from the second step on nothing is allocated.
+    struct Phase { char* blk = nullptr; size_t cap = 0, used = 0, virt = 0, need = 0; u32 epoch = 1; std::vector<void*> overflow; } ph;
+    bool resCarved = false;      // right / left / conn / cflag / status / cand point into the phase block (diet mode): never hipFree'd
 };
 static void s4cache_release(Device* d) { for (auto& c : d->s4cache) hipFree(c.first); d->s4cache.clear(); }
+static bool ws_phased(int id);
+static void* ph_carve(Device* d, size_t bytes);
 static void* ws_get(Device* d, int id, size_t bytes) {
     Device::Buf& b = d->ws[id];
+    if (d->diet && ws_phased(id)) {
+        if (b.p && b.epoch == d->ph.epoch && b.cap >= bytes) return b.p;
+        if (b.p && !b.epoch) { hipFree(b.p); }                                 // (allocated before the context went on the diet)
+        b.p = ph_carve(d, bytes + 256); b.cap = b.p ? bytes + 256 : 0; b.epoch = b.p ? d->ph.epoch : 0;
+        return b.p;
+    }
+    if (b.epoch) { b.p = nullptr; b.cap = 0; b.epoch = 0; }                   // (a carved piece from an earlier diet: not ours to free)
     if (b.cap < bytes || !b.p) {
         if (b.p) hipFree(b.p);
         b.p = nullptr; b.cap = 0;
@@ -100,7 +117,56 @@ static void* ws_get(Device* d, int id, size_t bytes) {
     }
     return b.p;
 }
-static void ws_free(Device* d, int id) { Device::Buf& b = d->ws[id]; if (b.p) hipFree(b.p); b.p = nullptr; b.cap = 0; }
+// workspace ids that live in the phase block in diet mode (see Device::Phase)
+static bool ws_phased(int id) {
+    switch (id) { case WS_PT_K0: case WS_PT_K1: case WS_WHERE: case WS_MINH: case WS_OCUR: case WS_PT_CNT: case WS_PT_BASE: case WS_PARTIAL: case WS_PT_OFF:
+                  case WS_KEYS: case WS_KEEP: case WS_POS: case WS_FINAL: case WS_SLOW: case WS_SLOW2: return true; default: return false; }
+}
+static void* ph_carve(Device* d, size_t bytes) {
+    Device::Phase& P = d->ph;
+    const size_t a = (P.virt + 255) & ~(size_t)255; P.virt = a + bytes; P.need = std::max(P.need, P.virt);
+    const size_t off = (P.used + 255) & ~(size_t)255;
+    if (P.blk && off + bytes <= P.cap) { P.used = off + bytes; return P.blk + off; }
+    void* p = nullptr;                                                     // (first step, or a phase that outgrew the block: a block of its own until the phase ends)
+    if (hipMalloc(&p, std::max<size_t>(bytes, 256)) != hipSuccess) {
+        (void)hipGetLastError(); s4cache_release(d);
+        if (P.blk && P.used == 0) { hipFree(P.blk); P.blk = nullptr; P.cap = 0; }      // (a block too small for this phase and not in use yet stands in the way)
+        if (hipMalloc(&p, std::max<size_t>(bytes, 256)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    }
+    P.overflow.push_back(p);
+    return p;
+}
+// a new phase: everything carved so far is dead (the caller has synchronised the stream); the block grows to what the largest phase so far needed
+static void ph_begin(Device* d, bool mayGrow = true) {
+    Device::Phase& P = d->ph;
+    for (void* p : P.overflow) hipFree(p);
+    P.overflow.clear();
+    if (mayGrow && P.need > P.cap) { if (P.blk) hipFree(P.blk); P.blk = nullptr; P.cap = 0; const size_t want = P.need + P.need / 64 + 4096; void* p = nullptr;
+                          if (hipMalloc(&p, want) == hipSuccess) { P.blk = (char*)p; P.cap = want; } else (void)hipGetLastError(); }
+    P.used = 0; P.virt = 0; P.epoch++;
+    for (int id = 0; id < WS_COUNT; id++) if (ws_phased(id)) { Device::Buf& b = d->ws[id]; if (b.epoch) { b.p = nullptr; b.cap = 0; b.epoch = 0; } }
+    if (d->resCarved) { d->right = d->left = nullptr; d->conn = d->cflag = nullptr; d->status = nullptr; d->cand = nullptr; d->cand_cap = 0; d->n_cand = 0; d->resCarved = false; }
+    d->final_edges = nullptr; d->n_final = 0;
+}
+static void ph_release(Device* d) {
+    Device::Phase& P = d->ph;
+    for (void* p : P.overflow) hipFree(p);
+    P.overflow.clear(); if (P.blk) hipFree(P.blk); P.blk = nullptr; P.cap = P.used = P.virt = P.need = 0; P.epoch++;
+    for (int id = 0; id < WS_COUNT; id++) { Device::Buf& b = d->ws[id]; if (b.epoch) { b.p = nullptr; b.cap = 0; b.epoch = 0; } }
+    if (d->resCarved) { d->right = d->left = nullptr; d->conn = d->cflag = nullptr; d->status = nullptr; d->cand = nullptr; d->cand_cap = 0; d->resCarved = false; }
+}
+static void ws_free(Device* d, int id) { Device::Buf& b = d->ws[id]; if (b.epoch) return;      // (carved: it goes with its phase)
+                                         if (b.p) hipFree(b.p); b.p = nullptr; b.cap = 0; }
+// the edge candidates: a block of their own, or a piece of the phase block in diet mode (then the old piece is simply left behind)
+static int cand_resize(Device* d, u64 ncap, u64 keep, std::string& err) {
+    EdgeCand* nc = nullptr;
+    if (d->diet) { nc = (EdgeCand*)ph_carve(d, ncap * sizeof(EdgeCand)); if (!nc) { err = "edge candidates: out of device memory"; return SAGE2OV_ERR_NOMEM; } }
+    else HIPCHK(hipMalloc(&nc, ncap * sizeof(EdgeCand)));
+    if (keep && d->cand) { HIPCHK(hipMemcpyAsync(nc, d->cand, keep * sizeof(EdgeCand), hipMemcpyDeviceToDevice, d->stream)); HIPCHK(hipStreamSynchronize(d->stream)); }
+    if (d->cand && !d->resCarved) hipFree(d->cand);
+    d->cand = nc; d->cand_cap = ncap; if (d->diet) d->resCarved = true;
+    return 0;
+}
 static void decide_diet(Device* d) {
     size_t fr = 0, to = 0; d->diet = false;
     if (hipMemGetInfo(&fr, &to) == hipSuccess && to) d->diet = (double)(d->N + 1) * 640.0 > 0.7 * (double)to;
@@ -164,9 +230,10 @@ Device* dev_create(int ordinal, const Options& opt, std::string& err) {
 static void rr_staging_release(Device* d);
 static void free_reads(Device* d) {
     rr_staging_release(d);                     // (pinned host buffers sized by the previous read set)
-    hipFree(d->reads); hipFree(d->right); hipFree(d->left); hipFree(d->conn); hipFree(d->cflag);
-    hipFree(d->status); hipFree(d->cand);     // slots / csr / final_edges live in the workspace arena
-    for (auto& b : d->ws) { if (b.p) hipFree(b.p); b.p = nullptr; b.cap = 0; }
+    hipFree(d->reads);
+    if (!d->resCarved) { hipFree(d->right); hipFree(d->left); hipFree(d->conn); hipFree(d->cflag); hipFree(d->status); hipFree(d->cand); }     // slots / csr / final_edges live in the workspace arena
+    ph_release(d);                                                              // (diet mode: the phase block and what was carved out of it)
+    for (auto& b : d->ws) { if (b.p && !b.epoch) hipFree(b.p); b.p = nullptr; b.cap = 0; b.epoch = 0; }
     s4cache_release(d);
     d->runStartFrac = 0.0; d->runStartsValid = false;          // (measured on the read set that just went: a new one decides for itself)
     d->readsLoc = nullptr; d->idOf = d->posOf = nullptr; d->statusP = nullptr; d->metaP = nullptr; d->mi1 = d->krec = nullptr; d->cand_cap = 0; d->n_cand = 0;
@@ -190,6 +257,12 @@ void dev_reset_timings(Device* d) { d->tm = DevTimings(); }
 // per-read results + candidate list: allocated when the probe pass first needs them (after the index build's transients are gone in diet mode)
 static int ensure_results(Device* d, std::string& err) {
     const u64 N = d->N;
+    if (!d->right && d->diet) {                                                // (pieces of the phase block: Device::Phase)
+        d->right = (u64*)ph_carve(d, (N + 1) * sizeof(u64)); d->left = (u64*)ph_carve(d, (N + 1) * sizeof(u64));
+        d->conn = (u32*)ph_carve(d, (N + 1) * sizeof(u32)); d->cflag = (u32*)ph_carve(d, (N + 1) * sizeof(u32)); d->status = (uint8_t*)ph_carve(d, N + 1);
+        d->resCarved = true;
+        if (!d->right || !d->left || !d->conn || !d->cflag || !d->status) { err = "result buffers: out of device memory"; return SAGE2OV_ERR_NOMEM; }
+    }
     if (!d->right) { HIPCHK(hipMalloc(&d->right, (N + 1) * sizeof(u64))); HIPCHK(hipMalloc(&d->left, (N + 1) * sizeof(u64)));
                      HIPCHK(hipMalloc(&d->conn, (N + 1) * sizeof(u32))); HIPCHK(hipMalloc(&d->cflag, (N + 1) * sizeof(u32))); HIPCHK(hipMalloc(&d->status, (N + 1))); }
     if (!d->cand && !d->diet) { d->cand_cap = 2 * N + 1024; HIPCHK(hipMalloc(&d->cand, d->cand_cap * sizeof(EdgeCand))); }      // (diet: sized by a counting pass of the reciprocal kernel)
@@ -371,7 +444,7 @@ static int build_locality_store(Device* d, std::string& err) {
     if (!order) d->runStartFrac = 0.0;
     // (the count travels to a pinned word while k_loc_scatter below runs: dev_build_index waits for the copy's event, not for the stream)
     if (d->runStartsValid) { HIPCHK(hipMemcpyAsync(d->h_runStarts, d->d_runStarts, 64 * sizeof(u64), hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipEventRecord(d->evRunStarts, d->stream)); }
-    if (d->diet) { HIPCHK(hipStreamSynchronize(d->stream)); ws_free(d, WS_MINH); ws_free(d, WS_OCUR); }       // the order's sort buffers (24 bytes per read) go before the tuples come
+    if (d->diet) { HIPCHK(hipStreamSynchronize(d->stream)); ph_begin(d, false); }       // the order's sort buffers (24 bytes per read) go before the tuples come: a phase of their own
     hipLaunchKernelGGL(k_loc_scatter, dim3(grid_for_capped((N + 1) * (d->S / 2), 256)), dim3(256), 0, d->stream, d->reads, po, (u64)N, d->S, rl);
     HIPCHK(hipGetLastError());
     return 0;
@@ -428,17 +501,18 @@ int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t
     const u64 N = d->N; if (!d->reads && !d->readsLoc) { err = "reads not resident"; return SAGE2OV_ERR_ARG; }
     s4cache_release(d);                                                   // (a new step 2: step 4's spare blocks must not stand in the way of steps 2-3; empty unless step 4 ran since)
     HIPCHK(hipEventRecord(d->ev[0], d->stream));                          // (the locality store is part of the build and of index_ms)
+    if (d->diet) {                                                            // phase A: the previous step's results go before the sort's buffers come (Device::Phase)
+        HIPCHK(hipStreamSynchronize(d->stream));
+        if (!d->resCarved) { hipFree(d->right); hipFree(d->left); hipFree(d->conn); hipFree(d->cflag); hipFree(d->status); hipFree(d->cand);     // (from before the context went on the diet)
+                             d->right = d->left = nullptr; d->conn = d->cflag = nullptr; d->status = nullptr; d->cand = nullptr; d->cand_cap = 0; d->n_cand = 0; }
+        ph_begin(d);
+    }
     if (d->reads) { int rc = build_locality_store(d, err); if (rc) return rc; }
     // (diet mode, second and later builds: the id-ordered store was released after the first one; the locality-ordered store and its tables are what
     //  this build would produce again -- the order is a function of the reads -- so they are kept)
     if (d->diet && d->reads && d->uniL) { HIPCHK(hipStreamSynchronize(d->stream)); hipFree(d->reads); d->reads = nullptr; }      // every later reader takes lengths from uniL
     const bool byPos = d->reads == nullptr;
-    if (d->diet) {                                                            // the previous step's results (per-read records, candidates, final edges: ~60 bytes per read) go before the sort's buffers come
-        HIPCHK(hipStreamSynchronize(d->stream));
-        hipFree(d->right); hipFree(d->left); hipFree(d->conn); hipFree(d->cflag); hipFree(d->status); hipFree(d->cand);
-        d->right = d->left = nullptr; d->conn = d->cflag = nullptr; d->status = nullptr; d->cand = nullptr; d->cand_cap = 0; d->n_cand = 0;
-        ws_free(d, WS_FINAL); d->final_edges = nullptr; d->n_final = 0; ws_free(d, WS_SLOW); ws_free(d, WS_SLOW2);
-    }
+    // (diet mode: the previous step's results -- per-read records, candidates, final edges: ~60 bytes per read -- went when this build began, ph_begin above)
     d->T = std::max<u64>(IX_W, (8 * N + IX_W - 1) / IX_W * IX_W);            // load <= 0.5, as hashTable.cpp:83 sizes it; whole windows
     // (tests: SAGE2OV_TEST_TABLE_SLOTS forces a larger table, e.g. beyond 2^32 slots -- slot indices are 64-bit, pair indices and window ids 32-bit)
     if (const char* ev = d->opt.get("SAGE2OV_TEST_TABLE_SLOTS")) { const u64 want = strtoull(ev, nullptr, 10); if (want > d->T) d->T = (want + IX_W - 1) / IX_W * IX_W; }
@@ -568,7 +642,7 @@ int dev_build_index(Device* d, uint64_t* slots_out, uint64_t* keys_out, uint64_t
     HIPCHK(hipEventRecord(d->ev[1], d->stream));
     HIPCHK(hipStreamSynchronize(d->stream));
     float ms = 0; hipEventElapsedTime(&ms, d->ev[0], d->ev[1]); d->tm.index_ms += ms;
-    if (d->diet) for (int id : {WS_PT_K0, WS_PT_K1, WS_WHERE, WS_MINH, WS_OCUR, WS_PT_CNT, WS_PT_BASE, WS_PARTIAL, WS_PT_OFF}) ws_free(d, id);     // the sort's buffers: ~150 bytes per read
+    if (d->diet) ph_begin(d);                                                 // phase B: the sort's buffers (~150 bytes per read) go, the step's results come
     *slots_out = d->T; *keys_out = d->n_keys; *csr_out = d->n_csr; *nlong_out = d->n_long;
     return 0;
 }
@@ -909,7 +983,7 @@ int dev_export_cands(Device* d, void* dst, uint64_t cap, std::string& err) {
 }
 int dev_set_cands(Device* d, const void* src, uint64_t n, std::string& err) {      // replace the candidate list (device source)
     HIPCHK(hipSetDevice(d->ordinal));
-    if (n > d->cand_cap) { hipFree(d->cand); d->cand = nullptr; d->cand_cap = n + 1024; HIPCHK(hipMalloc(&d->cand, d->cand_cap * sizeof(EdgeCand))); }
+    if (n > d->cand_cap) { int rc = cand_resize(d, n + 1024, 0, err); if (rc) return rc; }
     if (n) HIPCHK(hipMemcpyAsync(d->cand, src, n * sizeof(EdgeCand), hipMemcpyDeviceToDevice, d->stream));
     HIPCHK(hipStreamSynchronize(d->stream)); d->n_cand = n; return 0;
 }
@@ -925,11 +999,8 @@ int dev_replace_cand_tail(Device* d, uint64_t keep, const void* src, uint64_t n,
     HIPCHK(hipSetDevice(d->ordinal));
     if (keep > d->n_cand) { err = "candidate range out of bounds"; return SAGE2OV_ERR_ARG; }
     if (keep + n > d->cand_cap) {
-        EdgeCand* nc = nullptr; const u64 ncap = keep + n + 1024;
-        HIPCHK(hipMalloc(&nc, ncap * sizeof(EdgeCand)));
-        if (keep) HIPCHK(hipMemcpyAsync(nc, d->cand, keep * sizeof(EdgeCand), hipMemcpyDeviceToDevice, d->stream));
         HIPCHK(hipStreamSynchronize(d->stream));
-        hipFree(d->cand); d->cand = nc; d->cand_cap = ncap;
+        { int rc = cand_resize(d, keep + n + 1024, keep, err); if (rc) return rc; }
     }
     if (n) HIPCHK(hipMemcpyAsync(d->cand + keep, src, n * sizeof(EdgeCand), hipMemcpyDeviceToDevice, d->stream));
     HIPCHK(hipStreamSynchronize(d->stream)); d->n_cand = keep + n; return 0;
@@ -958,7 +1029,7 @@ int dev_reciprocal(Device* d, uint64_t emit_lo, uint64_t emit_hi, uint64_t* n_ov
     if (d->diet && emit_hi > emit_lo) {                                     // the list is sized by a counting pass (capacity 0: nothing is written, the cursor counts)
         hipLaunchKernelGGL(k_recip_emit, dim3(grid_for(emit_hi - emit_lo, 256 * EMIT_PER_THREAD)), dim3(256), 0, d->stream, N, d->readsLoc, d->S, d->uniL, d->right, d->left, d->statusP, d->idOf, (EdgeCand*)nullptr, (u64)0, d->d_counters, (u64)emit_lo, (u64)emit_hi);
         u64 want = 0; HIPCHK(hipMemcpyAsync(&want, d->d_counters, sizeof want, hipMemcpyDeviceToHost, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
-        if (want + 1024 > d->cand_cap || !d->cand) { hipFree(d->cand); d->cand = nullptr; d->cand_cap = want + 1024; HIPCHK(hipMalloc(&d->cand, d->cand_cap * sizeof(EdgeCand))); }
+        if (want + 1024 > d->cand_cap || !d->cand) { int rc = cand_resize(d, want + 1024, 0, err); if (rc) return rc; }
         HIPCHK(hipMemsetAsync(d->d_counters, 0, sizeof(u64), d->stream));
     }
     if (emit_hi > emit_lo)
@@ -1488,10 +1559,7 @@ int dev_reduce_device(Device* d, uint64_t min_unresolved, uint64_t* n_unresolved
     }
     u64 nsv = 0; if (nun) { int rc = scan_u32(d, svn, nun, svoff, &nsv, err); if (rc) return rc; }
     if (d->n_cand + nsv > d->cand_cap || d->opt.get("SAGE2OV_TEST_SMALL_BUFFERS")) {
-        EdgeCand* ncand = nullptr; const u64 ncap = d->n_cand + nsv + 1024;
-        HIPCHK(hipMalloc(&ncand, ncap * sizeof(EdgeCand)));
-        HIPCHK(hipMemcpyAsync(ncand, d->cand, d->n_cand * sizeof(EdgeCand), hipMemcpyDeviceToDevice, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
-        hipFree(d->cand); d->cand = ncand; d->cand_cap = ncap;
+        { int rc = cand_resize(d, d->n_cand + nsv + 1024, d->n_cand, err); if (rc) return rc; }
     }
     lap("final lists + marks");
     if (nun) hipLaunchKernelGGL(k_ra_emit, dim3(gb), dim3(256), 0, d->stream, ids, (u64)nun, offs, deg, ent, rm, svoff, d->cand, (u64)d->n_cand, (u64)d->cand_cap);
@@ -1569,7 +1637,8 @@ int dev_unresolved_ids(Device* d, std::vector<uint32_t>& ids, std::string& err) 
 int dev_meminfo(Device* d, uint64_t* out4, std::string& err) {
     HIPCHK(hipSetDevice(d->ordinal));
     size_t fr = 0, to = 0; HIPCHK(hipMemGetInfo(&fr, &to)); mem_sample(d);
-    u64 arena = 0; for (auto& b : d->ws) arena += b.cap;
+    u64 arena = 0; for (auto& b : d->ws) if (!b.epoch) arena += b.cap;
+    arena += d->ph.cap;                                                            // (diet mode: the phase block; what was carved out of it is not counted twice)
     if (d->opt.get("SAGE2OV_MEMINFO")) {                                         // diagnostic: the big buffers of the arena, by workspace id (enum order)
         fprintf(stderr, "[meminfo] free %.2f GB of %.2f, lowest %.2f, arena %.2f GB, N %llu, diet %d:", fr / 1e9, to / 1e9, d->memLow / 1e9, arena / 1e9, (unsigned long long)d->N, (int)d->diet);
         for (int x = 0; x < WS_COUNT; x++) if (d->ws[x].cap >= (64u << 20)) fprintf(stderr, " ws%d=%.2f", x, d->ws[x].cap / 1e9);
@@ -1620,10 +1689,7 @@ int dev_append_edges(Device* d, const EdgeCand* e, uint64_t n, std::string& err)
     HIPCHK(hipSetDevice(d->ordinal));
     if (n == 0) return 0;
     if (d->n_cand + n > d->cand_cap) {
-        EdgeCand* nc = nullptr; u64 ncap = d->n_cand + n + 1024;
-        HIPCHK(hipMalloc(&nc, ncap * sizeof(EdgeCand)));
-        HIPCHK(hipMemcpyAsync(nc, d->cand, d->n_cand * sizeof(EdgeCand), hipMemcpyDeviceToDevice, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
-        hipFree(d->cand); d->cand = nc; d->cand_cap = ncap;
+        { int rc = cand_resize(d, d->n_cand + n + 1024, d->n_cand, err); if (rc) return rc; }
     }
     HIPCHK(hipMemcpyAsync(d->cand + d->n_cand, e, n * sizeof(EdgeCand), hipMemcpyHostToDevice, d->stream)); HIPCHK(hipStreamSynchronize(d->stream));
     d->n_cand += n;
