@@ -998,15 +998,16 @@ def test_mid_length_reads_in_repeats_match_oracle(pd, k, monkeypatch):
 def test_memory_diet_mode_matches_reference(name, tmp_path, monkeypatch):
     """The mode a billion-read context runs in (BASELINE configs[4]): transient buffers released at the end of their phase, the id-ordered
     read store released once the locality-ordered one exists (uniform lengths only: g5 keeps it), no minimiser groups, per-read results and the candidate
-    list allocated when first needed and sized by a counting pass.  Same files as the reference's, twice in a row (the second index build starts without
-    the id-ordered store), and the arena is smaller than the default mode's."""
+    list allocated when first needed and sized by a counting pass.  Same files as the reference's, four times in a row (the second index build starts without
+    the id-ordered store; the phases' buffers are carved out of one block that the first two steps size and the later ones only reuse: sage2ov_device.hip,
+    Device::Phase), and the arena is smaller than the default mode's."""
     m = fx.golden(name)
     bases, off = fx.make_reads(m["synth"])
     def run(diet):
         monkeypatch.setenv("SAGE2OV_MEMORY_DIET", "1" if diet else "0")
         c = s2.Context(m["k"], device=0)
         c.reads_add_ascii(bases, off); c.reads_organize()
-        for rep in range(2):
+        for rep in range(4 if diet else 2):
             c.run_steps23()
             gp = str(tmp_path / f"d{int(diet)}{rep}.graph3"); c.graph_save(gp)
             assert fx.graph3_matches(gp, name), f"diet={diet} pass {rep}"
