@@ -55,6 +55,10 @@ struct Options {
     bool flag(const char* name) const { return get(name) != nullptr; }
     long long num(const char* name, long long dflt) const { const char* v = get(name); return v ? strtoll(v, nullptr, 10) : dflt; }
 };
+// the exploration order of the ranked reduce (sage2ov_walk.cpp, host code): rank[position] for the unresolved reads whose potential lists are `lists` / `lenp`
+void explore_order(const Options& O, const std::vector<uint32_t>& pos, const std::vector<const uint32_t*>& lists, const std::vector<uint32_t>& lenp, const std::vector<uint8_t>& hasCand,
+                   unsigned long long N, const std::vector<uint32_t>& startOrder, std::vector<uint32_t>& rank);
+
 
 struct Device;   // opaque, lives in sage2ov_device.hip
 
