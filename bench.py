@@ -440,7 +440,7 @@ def main():
                          # memory-side bytes per launch (PMC, profiles/probe_traffic.json) over the live kernel time: what the kernel really pulls
                          "traffic_achieved": (traffic * share / (kern_ms * 1e-3) / 1e9) if (traffic and kern_ms > 0) else None,
                          "traffic_frac": (traffic * share / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and kern_ms > 0) else None,
-                         "limiter": "latency of dependent memory round trips, then instruction issue: since round 4 the kernel answers 93 % of the reads in RUN MODE (off a verified frame and a ring of verified slots, up to 16 reads per step, strand changes by mirroring the ring: DESIGN.md 5.2) -- 283 VALU + 225 scalar wave-instructions and 19.9 memory-side line requests of 128 B per read (round 3: 691 + 484 and 62), i.e. the memory side moves x0.62 of the algorithmic bytes at 3.9 TB/s; 39 % of the wave cycles are the steps' three dependent round trips (table pair -> csr -> candidate dwords), 31 % the one read per minimiser (6.6 % of the reads) that takes the general path (111 table look-ups, 62 gathered candidates)",
+                         "limiter": "instruction issue, with the latency of dependent memory round trips behind it: since round 4 the kernel answers 93 % of the reads in RUN MODE (off a verified frame and a ring of verified slots, up to 16 reads per step, strand changes by mirroring the ring: DESIGN.md 5.2) -- 258 VALU + 214 scalar wave-instructions and 19.9 memory-side line requests of 128 B per read (round 3: 691 + 484 and 62), i.e. the memory side moves x0.62 of the algorithmic bytes at 4.0 TB/s; the PMC puts the VALU at 74 % and the scalar unit at 61 % busy (tools/pmc_wait.sh); 39 % of the wave cycles are the steps' three dependent round trips (table pair -> csr -> candidate dwords), 31 % the one read per minimiser (6.6 % of the reads) that takes the general path (111 table look-ups, 62 gathered candidates)",
                          # a probe pass is up to three launches of the kernel: a sample of 1/128 of the range, the rest (the instantiation the sample picked), and the
                          # few reads the first two listed; kernel_ms and the bytes are those of the whole pass (sum over its launches)
                          "valu": valu,
