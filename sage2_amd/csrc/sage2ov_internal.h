@@ -35,7 +35,10 @@ constexpr uint32_t HASH_THRESHOLD = 100;   // hashTable.cpp:76
 constexpr uint32_t CONN_LIMIT = 300;       // economyGraph.cpp:43
 
 struct EdgeCand { uint32_t from, to; uint32_t len; uint32_t type; };   // from < to, len already 20-bit masked
-struct Hit { uint32_t from; uint32_t to; int32_t len; uint16_t seq_hi; uint8_t type; uint8_t pad; uint32_t seq; };
+// a verified directional hit of an unresolved read (economyGraph.cpp:591-633).  16 bytes, one aligned 16-byte access (20 with a byte-sized type until round 4: the hit
+// lists of noisy data are 450 M entries that the probe kernel writes and two kernels of the reduce phase stream); seq: the hit's number among its read's hits
+struct alignas(16) Hit { uint32_t from; uint32_t to; int32_t len; uint32_t seq : 30; uint32_t type : 2; };
+static_assert(sizeof(Hit) == 16, "Hit: 16 bytes");
 struct FinalEdge { uint32_t from, to, len, len_twin; uint32_t type; };
 
 struct DevTimings { double index_ms = 0, probe_ms = 0, reciprocal_ms = 0, hits_ms = 0, convert_ms = 0, probe_kernel_ms = 0, organize_ms = 0, recip_cond_ms = 0, marks_ms = 0; uint64_t probe_launches = 0, slow_reads = 0, probe_fast_launches = 0; };
