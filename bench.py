@@ -97,6 +97,9 @@ def cpu_baseline(args, s2, fx):
     n = args.cpu_sample_reads
     cov = args.reads * args.read_len / args.genome
     pd = dict(seed=args.seed + 1000, genome_len=int(n * args.read_len / cov), n_reads=n, read_len=args.read_len)
+    if args.cpu_full:       # BASELINE.json configs[1] itself, every read of it (the generator parameters of the c2 digest): minutes of CPU, not part of the default run
+        n = 10_000_000
+        pd = dict(seed=2, genome_len=3 * n, n_reads=n, read_len=args.read_len)
     p = fx.synth_params(pd)
     try:
         cores = len(os.sched_getaffinity(0))
@@ -104,7 +107,7 @@ def cpu_baseline(args, s2, fx):
         cores = os.cpu_count() or 1
     # the GPU box gives one GPU's job a 16-core share of the host (more OpenMP threads only oversubscribe it)
     threads = args.cpu_threads if args.cpu_threads else min(cores, 16)
-    sample = f"{n} x {args.read_len} bp reads, k={args.k}, {pd['genome_len']} bp genome, seed {pd['seed']} (same coverage as the GPU workload)"
+    sample = f"{n} x {args.read_len} bp reads, k={args.k}, {pd['genome_len']} bp genome, seed {pd['seed']} " + ("(BASELINE.json configs[1], the whole input: --cpu-full)" if args.cpu_full else "(same coverage as the GPU workload)")
     tmp = tempfile.mkdtemp(prefix="sage2bench_")
     out = None
     try:
@@ -141,7 +144,7 @@ def cpu_baseline(args, s2, fx):
             # the same path on ONE thread on the SAME sample: the reference's cost per overlap grows with the size of its table, so
             # only equal samples compare -- and on this host its OpenMP loop is slower than its serial one (per-k-mer mallocs, utils.cpp:171-207)
             t1 = (C.c_double * 6)(); cc1 = (C.c_ulonglong * 3)()
-            if L.sage2ref_run_steps123(fa.encode(), args.k, 1, None, t1, cc1) == 0:
+            if not args.cpu_full and L.sage2ref_run_steps123(fa.encode(), args.k, 1, None, t1, cc1) == 0:
                 T1 = t1[2] + t1[3] + t1[4] + t1[5]
                 out["one_thread"] = dict(value=nov / T1, unit="overlaps/s", cores=1, sample="the same sample", seconds=dict(index=t1[2], initial=t1[3], reduce=t1[4], sort_convert=t1[5]))
             if hasattr(L, "sage2ref_run_step4") and ours4:
@@ -178,9 +181,9 @@ def cpu_baseline_subprocess(args):
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", "--reads", str(args.reads), "--read-len", str(args.read_len),
            "--k", str(args.k), "--genome", str(args.genome), "--seed", str(args.seed), "--cpu-sample-reads", str(args.cpu_sample_reads),
-           "--cpu-threads", str(args.cpu_threads)] + (["--cpu-port"] if args.cpu_port else [])
+           "--cpu-threads", str(args.cpu_threads)] + (["--cpu-port"] if args.cpu_port else []) + (["--cpu-full"] if args.cpu_full else [])
     try:
-        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=3000 if args.cpu_full else 1500)
         for line in reversed(r.stdout.decode().splitlines()):
             if line.startswith("{"):
                 return json.loads(line)
@@ -246,6 +249,7 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--cpu-port", action="store_true", help="time the CPU restatement instead of oracle/_ref")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-full", action="store_true", help="cpu_baseline on the WHOLE of BASELINE.json configs[1] (10 M reads) instead of the bounded sample: several minutes of host time, one-thread leg skipped")
     ap.add_argument("--no-scaling-model", action="store_true", help="skip the multi-GPU model and the extra build + probe pass without minimiser groups it measures (profiling runs)")
     ap.add_argument("--no-noisy-variant", action="store_true", help="skip the secondary line: the same workload with 0.1 %% substitution errors (SURVEY 8d)")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
