@@ -713,7 +713,7 @@ static ProbeArgs base_args(Device* d) {
     A.right = d->right; A.left = d->left; A.conn = d->conn; A.cflag = d->cflag; A.status = d->status; A.counters = d->d_counters;
     A.mi1 = d->mi1; A.TL = d->TL; A.krec = d->krec; A.uniL = d->uniL;
     A.chunkShift = (u32)FAST_CHUNK_LOG;      // (plan_fast_grid may double the positions per block visit)
-    A.noRun = d->opt.get("SAGE2OV_NO_RUN_MODE") ? 1u : 0u;
+    A.noRun = d->opt.get("SAGE2OV_NO_RUN_MODE") ? 1u : 0u; A.noParTail = d->opt.get("SAGE2OV_NO_PAR_TAIL") ? 1u : 0u;
     return A;
 }
 

@@ -1046,6 +1046,31 @@ def test_run_mode_of_the_fast_kernel_is_exact(pd, k, run_mode, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("form", ["parallel", "steps"])
+@pytest.mark.parametrize("tail", ["1", "2"])
+@pytest.mark.parametrize("pd,k", [
+    (dict(seed=181, genome_len=90000, n_reads=30000, read_len=150, err_ppm=1000), 40),                          # 50x, 0.1 % errors: a rejected hit or two per side, two to three rounds
+    (dict(seed=182, genome_len=90000, n_reads=30000, read_len=150, err_ppm=8000), 40),                          # 0.8 % errors: most hits rejected, rounds beyond the limit -> the steps
+    (dict(seed=183, genome_len=60000, n_reads=20000, read_len=150, read_len_min=110, err_ppm=1500), 31),        # mixed lengths: `longer` decides inside a window
+    (dict(seed=184, genome_len=30000, n_reads=30000, read_len=100, err_ppm=1000), 21),                          # 100x of 100-base reads: sides beyond 32 hits take the steps, the 4-word layout
+    (dict(seed=185, genome_len=60000, n_reads=20000, read_len=150, err_ppm=500, n_repeat_families=3, repeat_len=300, repeat_copies=8), 40),   # repeats: hits that disagree over their whole length
+    (dict(seed=186, genome_len=120000, n_reads=16000, read_len=123, err_ppm=2000), 25),                         # 16x, the 8-dword layout's longest read
+])
+def test_state_machine_in_its_parallel_form_is_exact(pd, k, tail, form, monkeypatch):
+    """The state machine of the fast kernel (economyGraph.cpp:95-438) evaluated as a fixed point over all hits of a side at once (kernels_probe_fast.inc: THE PARALLEL
+    FORM) and step by step (SAGE2OV_NO_PAR_TAIL), in the instantiation that sends every read through it (2) and in the one that sends the inconsistent ones (1): the
+    oracle's extension records, connection counts, edges and counters every way."""
+    monkeypatch.setenv("SAGE2OV_PROBE_TAIL", tail)
+    if form == "steps":
+        monkeypatch.setenv("SAGE2OV_NO_PAR_TAIL", "1")
+    bases, off = fx.make_reads(pd)
+    m = dict(k=k)
+    g, o = run_gpu(m, bases, off), run_oracle(m, bases, off)
+    assert_equals_oracle(g, o)
+    g.close(); o.close()
+
+
+@pytest.mark.gpu
 def test_a_key_in_more_than_2_to_20_reads(monkeypatch):
     """One k-mer as the prefix of 1.15 M different reads (an adaptor, a low-complexity stretch at human scale): the bucket's counter in the window kernel has 20 bits by
     default; the build notices the overflow and runs again with 30 bits of count instead of failing with SAGE2OV_ERR_LIMIT.  The bucket is long
