@@ -1055,6 +1055,8 @@ def test_run_mode_of_the_fast_kernel_is_exact(pd, k, run_mode, monkeypatch):
     (dict(seed=184, genome_len=30000, n_reads=30000, read_len=100, err_ppm=1000), 21),                          # 100x of 100-base reads: sides beyond 32 hits take the steps, the 4-word layout
     (dict(seed=185, genome_len=60000, n_reads=20000, read_len=150, err_ppm=500, n_repeat_families=3, repeat_len=300, repeat_copies=8), 40),   # repeats: hits that disagree over their whole length
     (dict(seed=186, genome_len=120000, n_reads=16000, read_len=123, err_ppm=2000), 25),                         # 16x, the 8-dword layout's longest read
+    (dict(seed=187, genome_len=80000, n_reads=16000, read_len=250, err_ppm=1000), 55),                          # the 16-dword layout: overhangs of up to 16 dwords per lane
+    (dict(seed=188, genome_len=80000, n_reads=20000, read_len=200, read_len_min=165, err_ppm=1500), 31),        # ... with mixed lengths
 ])
 def test_state_machine_in_its_parallel_form_is_exact(pd, k, tail, form, monkeypatch):
     """The state machine of the fast kernel (economyGraph.cpp:95-438) evaluated as a fixed point over all hits of a side at once (kernels_probe_fast.inc: THE PARALLEL
